@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the spherical-BA hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): residual+Jacobian evaluations per second.  Workload at N = 1: BASELINE config
+C3, "10M synthetic correspondences, full R|t (5-DoF) LM BA, 1xMI355X" -- 10^7 unit-sphere
+correspondences with per-match depths (64 algorithmic bytes per evaluation: 2 x 3 f64 unit-vector
+components + 2 f64 depths), f64 arithmetic.  A *step* is one pass of the hot path over the resident
+correspondences exactly as one LM iteration needs it: sweep kernel (residual + analytic Jacobian +
+Huber + reduction), finalize kernel, one all-reduce of the 24-double pack when N > 1, 192-byte D2H and
+host synchronisation.  Weak scaling: every rank holds 10^7 correspondences of the same two-view
+geometry, no data-path collective other than that all-reduce.
+
+One JSON line on rank 0.  `roofline` prices the sweep kernel alone against HBM (device time from HIP
+events recorded around each sweep launch on the problem's stream); `cpu_baseline` times the oracle's
+faithful dual-number loop on this box's host cores on a bounded sample (reported, not the target).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=10_000_000, help="correspondences per GPU")
+    ap.add_argument("--workload", choices=["rt", "rot"], default="rt",
+                    help="rt = config C3 (full R|t, per-match depths); rot = config C2 shape (rotation-only)")
+    ap.add_argument("--store", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--transport", choices=["auto", "native", "hook"], default="auto")
+    return ap.parse_args()
+
+
+def cpu_baseline(c, mode, per_match, sample, seconds):
+    """Oracle (kind "port"): faithful per-match dual-number functor + per-match trig + Huber corrector,
+    OpenMP over all host cores, on the first `sample` correspondences of the same workload."""
+    from oracle import oracle_py as orc
+    n = min(sample, c.x1.shape[0])
+    x1, x2 = c.x1[:n], c.x2[:n]
+    d12 = c.d12[:n] if per_match else None
+    cores = orc.num_procs()
+    orc.evaluate(mode, x1[:10000], x2[:10000], c.rot_init, c.tran_init, d12=None if d12 is None else d12[:10000])
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        orc.evaluate(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or passes >= 50:
+            break
+    faithful = n * passes / el
+    t0 = time.perf_counter()
+    orc.evaluate_hoisted(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12)
+    hoisted = n / (time.perf_counter() - t0)
+    return {"value": faithful, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} passes over the first {n} correspondences of the workload, faithful "
+                      f"dual-number loop (oracle/sba_oracle.cpp), {cores} OpenMP threads",
+            "optimised_cpu_value": hoisted}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+
+    from spherical_bundle_adjuster_amd import api, distributed, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    rt = a.workload == "rt"
+    mode = api.MODE_RT if rt else api.MODE_ROT
+    depth_mode = api.DEPTH_PER_MATCH if rt else api.DEPTH_UNIFORM
+    store = api.STORE_F64 if a.store == "f64" else api.STORE_F32
+    bytes_per_eval = {("rt", "f64"): 64, ("rt", "f32"): 40, ("rot", "f64"): 48, ("rot", "f32"): 24}[(a.workload, a.store)]
+    gen = synthetic.full_rt if rt else synthetic.rotation_only
+    seed = synthetic.BASE_SEED + (2 if rt else 1)
+    c = gen(a.n, seed=seed, shard=rank)
+
+    # hook transport needs the problem on torch's current stream; native/none use the shim's own stream
+    use_hook = world > 1 and a.transport == "hook"
+    stream = torch.cuda.current_stream().cuda_stream if use_hook else None
+    p = api.Problem(local_rank, stream=stream)
+    p.upload(c.x1, c.x2, c.d12 if rt else None, store=store)
+    transport = "none"
+    if world > 1:
+        transport = distributed.attach(p, prefer_native=a.transport != "hook")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rot, tran = c.rot_init.copy(), c.tran_init.copy()
+    for _ in range(a.warmup):
+        p.eval_pack(mode, rot, tran, depth_mode=depth_mode)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pack = p.eval_pack(mode, rot, tran, depth_mode=depth_mode)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only timing (HIP events on the problem's stream, same K sweeps) for the roofline figure
+    _, step_ms, sweep_ms = p.eval_timed(mode, rot, tran, depth_mode=depth_mode, repeat=a.steps)
+    # LM iterations per second of a real solve of this workload (secondary metric)
+    opt = api.default_lm_options(tran_param=api.TRAN_SPHERE if rt else api.TRAN_FREE)
+    r_s, t_s, summ = p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)
+    barrier()
+
+    if rank == 0:
+        total = a.n * world
+        value = total * a.steps / elapsed
+        achieved = a.n * bytes_per_eval / (sweep_ms * 1e-3) / 1e9
+        out = {
+            "metric": "residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("10M synthetic unit-sphere correspondences per GPU, full R|t sweep, per-match "
+                                    "depths (BASELINE config C3)" if rt and a.n == 10_000_000 else
+                                    f"{a.n} synthetic correspondences per GPU, {a.workload} sweep"),
+                       "correspondences_per_gpu": a.n, "mode": a.workload, "storage": a.store,
+                       "bytes_per_eval": bytes_per_eval, "allreduce": transport,
+                       "step": "sweep + finalize + all-reduce(24 f64) + D2H(192 B) + host sync"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "sweep_kernel", "kernel_ms": sweep_ms,
+                         "algorithmic_bytes_per_launch": a.n * bytes_per_eval},
+            "kernel_only_evals_per_s": a.n / (sweep_ms * 1e-3),
+            "device_step_ms": step_ms,
+            "lm": {"iters_per_s": summ.num_iterations / summ.seconds_total if summ.seconds_total > 0 else None,
+                   "iterations": summ.num_iterations, "termination": summ.termination,
+                   "rot_err_rad": float(np.abs(r_s - c.rot_true).max()),
+                   "tran_err": float(np.abs(t_s - c.tran_true).max())},
+            "cost": float(pack[22]),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(c, mode, rt, a.cpu_sample, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    p.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,257 @@
+/*
+ * sba_hip.h -- C-ABI drop-in boundary of the MI355X spherical bundle-adjustment hot path.
+ *
+ * What this replaces in the reference (whdlgp/spherical_bundle_adjuster, all citations
+ * relative to the reference tree):
+ *
+ *   - the four `add_residual` loops that build one Ceres residual block per match
+ *     (spherical_bundle_adjuster.cpp:870-889, :921-945, :978-1002, :1034-1063)
+ *       -> sba_problem_upload()            (one flat upload instead of 3 heap objects per match)
+ *   - one residual+Jacobian sweep of ceres::Solve over those blocks, i.e. the templated
+ *     functors (spherical_bundle_adjuster.cpp:843-868, :891-919, :947-976) pushed through
+ *     AutoDiffCostFunction + HuberLoss(1.0) and accumulated into J^T J / J^T r
+ *       -> sba_problem_eval() / sba_problem_eval_pack()
+ *   - `ceres::Solve(opt, &problem_rot|tran, &summary)` inside solve_problem()
+ *     (spherical_bundle_adjuster.cpp:183-217, options :334-338)
+ *       -> sba_problem_solve()             (Levenberg-Marquardt on the host, normal equations from the GPU)
+ *   - the d-only stage (spherical_bundle_adjuster.cpp:1004-1063)
+ *       -> sba_problem_solve_depths()
+ *   - pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
+ *       -> sba_keypoints_to_sphere()
+ *   - equi2cube::get_all (equi2cube.cpp:12-302)
+ *       -> sba_equi2cube()
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = SBA_OK, negative = error; the text of the
+ *     last error on the calling thread is returned by sba_last_error().
+ *   - no exceptions cross this boundary, no C++ or torch types appear in a signature.
+ *   - the caller owns every host array it passes in; the library owns the device buffers
+ *     inside the opaque handles.  Handles are not thread-safe.
+ *   - residual convention (spherical_bundle_adjuster.cpp:897-916):
+ *         e_i = d2 * x2_i - ( R(rot) * (d1 * x1_i) - tran )
+ *     with R(rot) the angle-axis rotation (Ceres AngleAxisRotatePoint semantics, including
+ *     its small-angle branch), robustified per 3-vector block by Huber(delta).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with SBA_ERR_NO_DEVICE.
+ */
+#ifndef SBA_HIP_H_
+#define SBA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBA_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------ */
+enum {
+  SBA_OK = 0,
+  SBA_ERR_INVALID_ARG = -1,
+  SBA_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime unusable                     */
+  SBA_ERR_HIP = -3,         /* a HIP call failed (text in sba_last_error)               */
+  SBA_ERR_NOT_UPLOADED = -4,
+  SBA_ERR_COMM = -5,        /* RCCL / user all-reduce hook failed                        */
+  SBA_ERR_NUMERIC = -6,     /* non-finite normal equations, singular system             */
+  SBA_ERR_UNSUPPORTED = -7
+};
+
+/* ---- which parameter block is free (= which reference functor is evaluated) ---------- */
+enum {
+  SBA_MODE_ROT = 0,  /* ba_spherical_costfunctor_rot_only  (.cpp:891-919): rot free, tran frozen */
+  SBA_MODE_TRAN = 1, /* ba_spherical_costfunctor_tran_only (.cpp:947-976): tran free, rot frozen */
+  SBA_MODE_RT = 2    /* ba_spherical_costfunctor (.cpp:843-868) with d held fixed: rot+tran free */
+};
+
+/* ---- where d1,d2 come from ----------------------------------------------------------- */
+enum {
+  SBA_DEPTH_UNIFORM = 0,  /* two scalars for every match: what the reference actually does,
+                             init_d[0][0] / init_d[1][0] (.cpp:941-942, :998-999)          */
+  SBA_DEPTH_PER_MATCH = 1 /* d12[i][0], d12[i][1] per match (.cpp:887, the joint functor)  */
+};
+
+/* ---- storage type of the device-resident unit vectors -------------------------------- */
+enum {
+  SBA_STORE_F64 = 0, /* 48 B / correspondence (64 B with per-match depths): reference-faithful */
+  SBA_STORE_F32 = 1  /* 24 B / correspondence (32 B): arithmetic stays f64                    */
+};
+
+/* ---- translation parameterisation in SBA_MODE_RT / SBA_MODE_TRAN ---------------------- */
+enum {
+  SBA_TRAN_FREE = 0,   /* 3 free components, additive update (reference behaviour)            */
+  SBA_TRAN_SPHERE = 1  /* 5-DoF: tran stays on the sphere |tran| = const, 2-dim tangent update */
+};
+
+/* Indices into the 24-double device pack (the thing that is all-reduced across GPUs).     */
+enum {
+  SBA_PACK_HAA = 0,   /* [0..5]  upper triangle of sum w A^T A : 00 01 02 11 12 22          */
+  SBA_PACK_HAT = 6,   /* [6..14] sum w A^T  (3x3 row-major: row = rot index, col = tran idx) */
+  SBA_PACK_SW = 15,   /* sum w            (H_tt = SW * I3)                                  */
+  SBA_PACK_GA = 16,   /* [16..18] sum w A^T e                                               */
+  SBA_PACK_GT = 19,   /* [19..21] sum w e                                                   */
+  SBA_PACK_COST = 22, /* 1/2 sum rho(|e|^2)                                                 */
+  SBA_PACK_NOUT = 23, /* number of blocks in Huber's outlier region (as a double)           */
+  SBA_PACK_SIZE = 24
+};
+
+/* Expanded normal equations over the parameter order [rot0 rot1 rot2 tran0 tran1 tran2].  */
+typedef struct sba_normal_eq {
+  double H[36];      /* row-major symmetric 6x6 = sum rho' J^T J; unused blocks are zero     */
+  double g[6];       /* sum rho' J^T e                                                       */
+  double cost;       /* 1/2 sum rho(|e|^2)   (what Ceres reports as the cost)                */
+  double sum_w;      /* sum rho'                                                             */
+  double n_outlier;  /* blocks with |e|^2 > delta^2                                          */
+} sba_normal_eq;
+
+/* Levenberg-Marquardt options; defaults (sba_lm_options_default) restate the Ceres defaults
+ * that govern the reference's solve (spherical_bundle_adjuster.cpp:334-338 sets only
+ * max_num_iterations = 50, the linear solver, stdout logging and the thread count).       */
+typedef struct sba_lm_options {
+  int max_num_iterations;             /* 50  (.cpp:336)                                     */
+  double initial_trust_region_radius; /* 1e4                                               */
+  double max_trust_region_radius;     /* 1e16                                              */
+  double min_trust_region_radius;     /* 1e-32                                             */
+  double min_relative_decrease;       /* 1e-3                                              */
+  double min_lm_diagonal;             /* 1e-6                                              */
+  double max_lm_diagonal;             /* 1e32                                              */
+  double function_tolerance;          /* 1e-6                                              */
+  double gradient_tolerance;          /* 1e-10                                             */
+  double parameter_tolerance;         /* 1e-8                                              */
+  int jacobi_scaling;                 /* 1                                                 */
+  double huber_delta;                 /* 1.0 (.cpp:887,:943,:1000); <= 0 disables the loss */
+  int tran_param;                     /* SBA_TRAN_FREE (reference) or SBA_TRAN_SPHERE       */
+  int verbose;                        /* 1 = per-iteration line on stdout (.cpp:337)        */
+} sba_lm_options;
+
+enum {
+  SBA_TERM_CONVERGENCE_FUNCTION = 1,
+  SBA_TERM_CONVERGENCE_GRADIENT = 2,
+  SBA_TERM_CONVERGENCE_PARAMETER = 3,
+  SBA_TERM_NO_CONVERGENCE = 4,     /* iteration limit                                       */
+  SBA_TERM_MIN_RADIUS = 5,
+  SBA_TERM_FAILURE = 6
+};
+
+typedef struct sba_lm_summary {
+  int termination;            /* SBA_TERM_*                                                */
+  int num_iterations;         /* LM iterations run (successful + unsuccessful)             */
+  int num_successful_steps;
+  int num_evaluations;        /* residual+Jacobian sweeps over the correspondences         */
+  double initial_cost;
+  double final_cost;
+  double final_gradient_max_norm;
+  double final_radius;
+  double seconds_total;       /* wall clock of the whole solve                             */
+  double seconds_eval;        /* of which: waiting for the device sweeps                   */
+} sba_lm_summary;
+
+typedef struct sba_problem sba_problem; /* opaque: one shard of correspondences on one GPU  */
+
+/* User all-reduce hook (sum, in place) over `count` doubles at device address `device_buf`,
+ * to be enqueued on HIP stream `stream`.  Lets a host that already owns a communicator
+ * (e.g. torch.distributed) supply the exchange; see also sba_problem_comm_init_rank.        */
+typedef int (*sba_allreduce_fn)(void* device_buf, size_t count, void* stream, void* user);
+
+/* ---- library ------------------------------------------------------------------------- */
+int sba_abi_version(void);
+const char* sba_last_error(void);
+int sba_device_count(int* count);
+void sba_lm_options_default(sba_lm_options* opt);
+
+/* ---- problem life cycle ---------------------------------------------------------------- */
+/* device: HIP ordinal.  stream: an existing hipStream_t to launch on, or NULL to let the
+ * problem create its own non-blocking stream.                                              */
+int sba_problem_create(sba_problem** out, int device, void* stream);
+int sba_problem_destroy(sba_problem* p);
+
+/* Upload n correspondences.  left_xyz / right_xyz: packed double[3n], exactly
+ * `std::vector<cv::Point3d>::data()` of key_point_left_rect / key_point_right_rect
+ * (spherical_bundle_adjuster.cpp:286-298).  d12: NULL, or double[2n] =
+ * `std::vector<std::array<double,2>>::data()` (init_d, .cpp:311-327) for per-match depths.
+ * The arrays are copied (and re-laid-out as planes) once; they are not referenced afterwards.
+ * n == 0 is legal (every eval then returns zeros).                                          */
+int sba_problem_upload(sba_problem* p, const double* left_xyz, const double* right_xyz,
+                       const double* d12, size_t n, int store);
+
+/* Same, from arrays already resident on this problem's device (same AoS layouts).          */
+int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const void* right_xyz_dev,
+                              const void* d12_dev, size_t n, int store);
+
+int sba_problem_size(const sba_problem* p, size_t* n);
+
+/* ---- one residual + Jacobian sweep ------------------------------------------------------ */
+/* Evaluates all local correspondences at (rot, tran), reduces on the device, all-reduces if a
+ * communicator/hook is installed, and returns the expanded normal equations.  depth_mode
+ * SBA_DEPTH_UNIFORM uses (d1, d2) for every match; SBA_DEPTH_PER_MATCH uses the uploaded d12
+ * (d1, d2 ignored).  huber_delta <= 0 means no robustifier.  Synchronous.                  */
+int sba_problem_eval(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                     const double tran[3], double d1, double d2, double huber_delta,
+                     sba_normal_eq* out);
+
+/* As above but returns the raw 24-double pack (SBA_PACK_* layout).                         */
+int sba_problem_eval_pack(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                          const double tran[3], double d1, double d2, double huber_delta,
+                          double pack[SBA_PACK_SIZE]);
+
+/* Enqueue `repeat` back-to-back sweeps without host synchronisation in between and time them with
+ * HIP events recorded on the problem's stream: *mean_step_ms = (sweep + finalize [+ all-reduce]) per
+ * repeat, *mean_sweep_ms = the sweep kernel alone (events bracket each sweep launch).  Either output
+ * pointer may be NULL.  The last sweep's pack is returned.  This is bench.py's timing primitive.  */
+int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                           const double tran[3], double d1, double d2, double huber_delta,
+                           int repeat, double pack[SBA_PACK_SIZE], double* mean_step_ms,
+                           double* mean_sweep_ms);
+
+/* Host-only: expand a pack into the 6x6 system (no device needed).                         */
+int sba_expand_pack(int mode, const double pack[SBA_PACK_SIZE], sba_normal_eq* out);
+
+/* ---- Levenberg-Marquardt solve (replaces ceres::Solve for the rot / tran / joint stage) -- */
+/* rot and tran are updated in place like init_rot / init_tran in the reference
+ * (spherical_bundle_adjuster.cpp:202-209).                                                  */
+int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], double tran[3],
+                      double d1, double d2, const sba_lm_options* opt, sba_lm_summary* summary);
+
+/* d-only stage (spherical_bundle_adjuster.cpp:1004-1063): per match an independent bounded
+ * 2-parameter LM on (d1_i, d2_i) with regularisers lambda*exp(-c*d); needs per-match depths
+ * uploaded (they are the initial values) and updates them on the device.  d12_out (double[2n],
+ * may be NULL) receives the result.                                                         */
+int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3],
+                             double lambda, double c, int max_iterations, double* d12_out,
+                             double* total_cost);
+
+/* ---- multi-GPU: one process (and one sba_problem) per GPU, correspondences sharded ------ */
+/* Option A: native RCCL.  Rank 0 calls sba_comm_unique_id, ships the 128 bytes to the other
+ * ranks by any host channel, then every rank calls sba_problem_comm_init_rank.  After that
+ * every eval / solve all-reduces the 24-double pack once (ncclAllReduce, ncclDouble, ncclSum). */
+#define SBA_COMM_ID_BYTES 128
+int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]);
+int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]);
+/* Option B: user hook (e.g. torch.distributed.all_reduce on a tensor aliasing device_buf).  */
+int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
+/* Device address of the 24-double result pack the hook / RCCL operates on.                  */
+int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);
+
+/* ---- callers / data formats either side of the path ------------------------------------- */
+/* pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298).  keypoints: n records of
+ * `stride_bytes` bytes whose first two floats are pt.x, pt.y (cv::KeyPoint: stride 28).
+ * out_xyz: double[3n] host array (cv::Point3d layout).                                       */
+int sba_keypoints_to_sphere(int device, const void* keypoints, size_t n, size_t stride_bytes,
+                            int im_width, int im_height, double* out_xyz);
+
+/* ERP -> cubemap strip (equi2cube.cpp:12-302).  erp: H x W x 3 bytes (8UC3, row-major, host).
+ * out: cube_size x (6*cube_size) x 3 bytes, face order left,front,right,back,top,bottom
+ * (equi2cube.cpp:292-298).  Source indices are clamped into the image (the reference does not
+ * clamp, equi2cube.cpp:47-50; it can only differ at the exact pole).                        */
+int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, int cube_size,
+                  uint8_t* out);
+/* Batched, device-resident form: erp_dev = batch x H x W x 3 bytes, out_dev = batch x S x 6S x 3
+ * bytes, both on `device`; enqueued on `stream` (NULL = the default stream), not synchronised.  */
+int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
+                         int cube_size, int batch, void* out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBA_HIP_H_ */

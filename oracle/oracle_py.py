@@ -1,0 +1,164 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (parity unpinned, see sba_oracle.cpp header).
+
+ctypes binding of oracle/libsba_oracle.so.  Importable only from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg; the product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "libsba_oracle.so"
+
+MODE_ROT, MODE_TRAN, MODE_RT = 0, 1, 2
+
+
+class LmOptions(C.Structure):   # same field order as sba_lm_options
+    _fields_ = [("max_num_iterations", C.c_int),
+                ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double),
+                ("jacobi_scaling", C.c_int),
+                ("huber_delta", C.c_double),
+                ("tran_param", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class LmSummary(C.Structure):
+    _fields_ = [("termination", C.c_int), ("num_iterations", C.c_int), ("num_successful_steps", C.c_int),
+                ("num_evaluations", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("final_gradient_max_norm", C.c_double), ("final_radius", C.c_double)]
+
+
+def default_options(**kw) -> LmOptions:
+    o = LmOptions(50, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 1, 1.0, 0, 0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+@dataclass
+class Eval:
+    H: np.ndarray
+    g: np.ndarray
+    cost: float
+    sum_w: float
+    n_outlier: float
+
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            build()
+        _lib = C.CDLL(str(LIB))
+        _lib.orc_num_procs.restype = C.c_int
+        _lib.orc_equi2cube.restype = C.c_long
+        _lib.orc_lm_solve.restype = C.c_int
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def num_procs() -> int:
+    return lib().orc_num_procs()
+
+
+def point(mode, cam1, cam2, rot, tran, d1, d2):
+    """Residual e (3,) and Jacobian J (3,6) over [rot|tran] of ONE residual block (dual numbers)."""
+    e, J = np.zeros(3), np.zeros((3, 6))
+    lib().orc_point(C.c_int(mode), _p(_f64(cam1)), _p(_f64(cam2)), _p(_f64(rot)), _p(_f64(tran)),
+                    C.c_double(d1), C.c_double(d2), _p(e), _p(J))
+    return e, J
+
+
+def huber(a: float, s: float) -> np.ndarray:
+    rho = np.zeros(3)
+    lib().orc_huber(C.c_double(a), C.c_double(s), _p(rho))
+    return rho
+
+
+def rotate(w, p) -> np.ndarray:
+    out = np.zeros(3)
+    lib().orc_rotate(_p(_f64(w)), _p(_f64(p)), _p(out))
+    return out
+
+
+def _eval(fn, mode, x1, x2, d12, rot, tran, d1, d2, delta, threads) -> Eval:
+    x1, x2 = _f64(x1).reshape(-1, 3), _f64(x2).reshape(-1, 3)
+    n = x1.shape[0]
+    per_match = d12 is not None
+    dd = _f64(d12).reshape(-1, 2) if per_match else np.zeros((1, 2))
+    out = np.zeros(45)
+    fn(C.c_int(mode), C.c_int(1 if per_match else 0), _p(x1), _p(x2), _p(dd), C.c_size_t(n), _p(_f64(rot)),
+       _p(_f64(tran)), C.c_double(d1), C.c_double(d2), C.c_double(delta), C.c_int(threads), _p(out))
+    return Eval(out[:36].reshape(6, 6).copy(), out[36:42].copy(), float(out[42]), float(out[43]), float(out[44]))
+
+
+def evaluate(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, delta=1.0, d12=None, threads=0) -> Eval:
+    """Faithful loop: per-match functor through dual numbers + per-match trig, Huber corrector,
+    long-double accumulation (reference .cpp:843-1002 as Ceres would evaluate it)."""
+    return _eval(lib().orc_eval, mode, x1, x2, d12, rot, tran, d1, d2, delta, threads)
+
+
+def evaluate_hoisted(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, delta=1.0, d12=None, threads=0) -> Eval:
+    """Optimised-CPU loop: rotation matrices hoisted, analytic per-match arithmetic in double."""
+    return _eval(lib().orc_eval_hoisted, mode, x1, x2, d12, rot, tran, d1, d2, delta, threads)
+
+
+def lm_solve(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, d12=None, options: LmOptions | None = None,
+             threads=0, faithful=True):
+    x1, x2 = _f64(x1).reshape(-1, 3), _f64(x2).reshape(-1, 3)
+    n = x1.shape[0]
+    per_match = d12 is not None
+    dd = _f64(d12).reshape(-1, 2) if per_match else np.zeros((1, 2))
+    rot, tran = _f64(rot).copy(), _f64(tran).copy()
+    o = options if options is not None else default_options()
+    s = LmSummary()
+    rc = lib().orc_lm_solve(C.c_int(mode), C.c_int(1 if per_match else 0), _p(x1), _p(x2), _p(dd), C.c_size_t(n),
+                            _p(rot), _p(tran), C.c_double(d1), C.c_double(d2), C.byref(o), C.c_int(threads),
+                            C.c_int(1 if faithful else 0), C.byref(s))
+    return rot, tran, s, rc
+
+
+def keypoints_to_sphere(kp: np.ndarray, im_w: int, im_h: int) -> np.ndarray:
+    kp = np.ascontiguousarray(kp)
+    n = kp.shape[0]
+    out = np.zeros((n, 3))
+    lib().orc_keypoints_to_sphere(_p(kp), C.c_size_t(n), C.c_size_t(kp.strides[0] if n else 28), C.c_int(im_w),
+                                  C.c_int(im_h), _p(out))
+    return out
+
+
+def equi2cube(im: np.ndarray, cube: int, clamp: bool = True):
+    im = np.ascontiguousarray(im, dtype=np.uint8)
+    out = np.zeros((cube, 6 * cube, 3), dtype=np.uint8)
+    clamped = lib().orc_equi2cube(_p(im), C.c_int(im.shape[0]), C.c_int(im.shape[1]), C.c_int(cube),
+                                  C.c_int(1 if clamp else 0), _p(out))
+    return out, int(clamped)

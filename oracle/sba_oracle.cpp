@@ -1,0 +1,528 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED AT THE CERES BOUNDARY.
+//
+// CPU restatement of the reference's spherical bundle-adjustment hot path, used ONLY by tests/,
+// __graft_entry__.smoke() and the cpu_baseline leg of bench.py as the checker / timed baseline.
+// Nothing under spherical_bundle_adjuster_amd/ may include, link or call this file.
+//
+// Why "parity unpinned": the reference (whdlgp/spherical_bundle_adjuster) delegates the Jacobians,
+// the rotation, the robust loss and the whole minimiser to Ceres Solver (find_package(Ceres) with
+// no version pin, CMakeLists.txt:12) and ships no test, golden vector or data file that touches the
+// BA path (test/feature_test.cpp exercises the matchers only).  Neither Ceres nor OpenCV exist in
+// this image, so the reference cannot be built or run here.  What follows restates
+//   - the reference's own functor bodies, line by line in meaning (citations on each function), and
+//   - Ceres' documented public semantics for AngleAxisRotatePoint, AutoDiffCostFunction (forward-mode
+//     dual numbers), HuberLoss + Corrector, and the default Levenberg-Marquardt trust-region loop.
+// It is cross-checked in tests/ against an independent numpy analytic Jacobian, torch f64 autograd
+// and central finite differences, but not against a running Ceres.
+//
+// Build: make -C oracle   (g++ -O2 -fopenmp, see oracle/Makefile)
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ---- forward-mode dual number: stands in for ceres::Jet<double, N> ---------------------------------
+template <int N>
+struct Dual {
+  double v;
+  double d[N];
+  Dual() : v(0) { for (int i = 0; i < N; ++i) d[i] = 0; }
+  Dual(double x) : v(x) { for (int i = 0; i < N; ++i) d[i] = 0; }  // NOLINT: implicit like Jet
+  static Dual var(double x, int k) { Dual r(x); r.d[k] = 1.0; return r; }
+};
+template <int N> Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; const double inv = 1.0 / b.v; r.v = a.v * inv; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
+template <int N> Dual<N> operator*(double a, const Dual<N>& b) { return Dual<N>(a) * b; }
+template <int N> Dual<N> operator*(const Dual<N>& a, double b) { return a * Dual<N>(b); }
+template <int N> Dual<N> operator-(const Dual<N>& a, double b) { return a - Dual<N>(b); }
+template <int N> Dual<N> operator-(double a, const Dual<N>& b) { return Dual<N>(a) - b; }
+template <int N> Dual<N> operator+(const Dual<N>& a, double b) { return a + Dual<N>(b); }
+template <int N> bool operator>(const Dual<N>& a, double b) { return a.v > b; }
+template <int N> Dual<N> sqrt(const Dual<N>& a) { Dual<N> r; r.v = std::sqrt(a.v); const double k = 0.5 / r.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * k; return r; }
+template <int N> Dual<N> sin(const Dual<N>& a) { Dual<N> r; r.v = std::sin(a.v); const double c = std::cos(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c; return r; }
+template <int N> Dual<N> cos(const Dual<N>& a) { Dual<N> r; r.v = std::cos(a.v); const double s = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int N> Dual<N> exp(const Dual<N>& a) { Dual<N> r; r.v = std::exp(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * r.v; return r; }
+inline double sqrt(double a) { return std::sqrt(a); }
+inline double sin(double a) { return std::sin(a); }
+inline double cos(double a) { return std::cos(a); }
+inline double exp(double a) { return std::exp(a); }
+inline double value_of(double a) { return a; }
+template <int N> double value_of(const Dual<N>& a) { return a.v; }
+
+// ---- Ceres AngleAxisRotatePoint semantics (call sites: spherical_bundle_adjuster.cpp:857,908,965,1019)
+// Rodrigues' formula on the unit axis; for theta^2 <= DBL_EPSILON the first-order form p + w x p, so
+// that derivatives stay finite at the origin.
+template <typename T>
+void angle_axis_rotate(const T w[3], const T p[3], T out[3]) {
+  const T th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (th2 > DBL_EPSILON) {
+    const T th = sqrt(th2);
+    const T c = cos(th), s = sin(th);
+    const T inv = T(1.0) / th;
+    const T a[3] = {w[0] * inv, w[1] * inv, w[2] * inv};
+    const T axp[3] = {a[1] * p[2] - a[2] * p[1], a[2] * p[0] - a[0] * p[2], a[0] * p[1] - a[1] * p[0]};
+    const T k = (a[0] * p[0] + a[1] * p[1] + a[2] * p[2]) * (T(1.0) - c);
+    for (int i = 0; i < 3; ++i) out[i] = p[i] * c + axp[i] * s + a[i] * k;
+  } else {
+    const T wxp[3] = {w[1] * p[2] - w[2] * p[1], w[2] * p[0] - w[0] * p[2], w[0] * p[1] - w[1] * p[0]};
+    for (int i = 0; i < 3; ++i) out[i] = p[i] + wxp[i];
+  }
+}
+
+// ---- the residual model common to all four functors ---------------------------------------------
+// spherical_bundle_adjuster.cpp:846-865 (joint), :897-916 (rot-only), :953-973 (tran-only),
+// :1008-1027 (d-only):  X1 = cam1*d[0]; X2 = cam2*d[1]; X1r = R(r) X1; X1_RT = X1r - t;
+// residual = X2 - X1_RT.
+template <typename T>
+void reprojection_residual(const double cam1[3], const double cam2[3], const T d[2], const T r[3],
+                           const T t[3], T res[3]) {
+  T X1[3], X2[3], X1r[3];
+  for (int i = 0; i < 3; ++i) { X1[i] = cam1[i] * d[0]; X2[i] = cam2[i] * d[1]; }
+  angle_axis_rotate(r, X1, X1r);
+  for (int i = 0; i < 3; ++i) {
+    const T x1_rt = X1r[i] - t[i];
+    res[i] = X2[i] - x1_rt;
+  }
+}
+
+enum { MODE_ROT = 0, MODE_TRAN = 1, MODE_RT = 2 };
+
+// residual e[3] and Jacobian J[3][6] over [rot | tran]; columns of frozen blocks are zero.
+void point_residual_jacobian(int mode, const double cam1[3], const double cam2[3], const double rot[3],
+                             const double tran[3], double d1, double d2, double e[3], double J[18]) {
+  std::memset(J, 0, 18 * sizeof(double));
+  if (mode == MODE_ROT) {          // AutoDiffCostFunction<rot_only, 3, 3>  (.cpp:931)
+    typedef Dual<3> T;
+    T r[3] = {T::var(rot[0], 0), T::var(rot[1], 1), T::var(rot[2], 2)};
+    T t[3] = {T(tran[0]), T(tran[1]), T(tran[2])};
+    T d[2] = {T(d1), T(d2)};
+    T res[3];
+    reprojection_residual(cam1, cam2, d, r, t, res);
+    for (int i = 0; i < 3; ++i) { e[i] = res[i].v; for (int k = 0; k < 3; ++k) J[6 * i + k] = res[i].d[k]; }
+  } else if (mode == MODE_TRAN) {  // AutoDiffCostFunction<tran_only, 3, 3> (.cpp:988)
+    typedef Dual<3> T;
+    T r[3] = {T(rot[0]), T(rot[1]), T(rot[2])};
+    T t[3] = {T::var(tran[0], 0), T::var(tran[1], 1), T::var(tran[2], 2)};
+    T d[2] = {T(d1), T(d2)};
+    T res[3];
+    reprojection_residual(cam1, cam2, d, r, t, res);
+    for (int i = 0; i < 3; ++i) { e[i] = res[i].v; for (int k = 0; k < 3; ++k) J[6 * i + 3 + k] = res[i].d[k]; }
+  } else {                         // joint functor (.cpp:880) with the d block held constant
+    typedef Dual<6> T;
+    T r[3] = {T::var(rot[0], 0), T::var(rot[1], 1), T::var(rot[2], 2)};
+    T t[3] = {T::var(tran[0], 3), T::var(tran[1], 4), T::var(tran[2], 5)};
+    T d[2] = {T(d1), T(d2)};
+    T res[3];
+    reprojection_residual(cam1, cam2, d, r, t, res);
+    for (int i = 0; i < 3; ++i) { e[i] = res[i].v; for (int k = 0; k < 6; ++k) J[6 * i + k] = res[i].d[k]; }
+  }
+}
+
+// ---- ceres::HuberLoss(a)::Evaluate + Corrector (loss attached at .cpp:887, :943, :1000) -------------
+// rho = {rho(s), rho'(s), rho''(s)}.  rho'' <= 0 everywhere for Huber, so the corrector reduces to
+// scaling residuals and Jacobian rows by sqrt(rho').
+void huber_evaluate(double a, double s, double rho[3]) {
+  const double b = a * a;
+  if (s > b) {
+    const double r = std::sqrt(s);
+    rho[0] = 2.0 * a * r - b;
+    rho[1] = std::max(DBL_MIN, a / r);
+    rho[2] = -rho[1] / (2.0 * s);
+  } else {
+    rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+struct NormalEq {
+  long double H[36], g[6], cost, sum_w, n_out;
+  NormalEq() { std::memset(this, 0, sizeof(*this)); }
+  void add(const NormalEq& o) {
+    for (int i = 0; i < 36; ++i) H[i] += o.H[i];
+    for (int i = 0; i < 6; ++i) g[i] += o.g[i];
+    cost += o.cost; sum_w += o.sum_w; n_out += o.n_out;
+  }
+};
+
+// One residual block as Ceres evaluates it: functor through dual numbers, loss, corrector, then
+// J^T J / J^T e accumulation (in long double so the oracle is far more accurate than any f64 sum order).
+inline void accumulate_block(int mode, const double cam1[3], const double cam2[3], const double rot[3],
+                             const double tran[3], double d1, double d2, double delta, NormalEq* ne) {
+  double e[3], J[18];
+  point_residual_jacobian(mode, cam1, cam2, rot, tran, d1, d2, e, J);
+  const double s = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+  double rho[3] = {s, 1.0, 0.0};
+  if (delta > 0.0) huber_evaluate(delta, s, rho);
+  const double scale = std::sqrt(rho[1]);   // Corrector: rho'' <= 0 branch
+  for (int i = 0; i < 3; ++i) { e[i] *= scale; for (int k = 0; k < 6; ++k) J[6 * i + k] *= scale; }
+  for (int a = 0; a < 6; ++a) {
+    for (int b = 0; b < 6; ++b) {
+      long double acc = 0;
+      for (int i = 0; i < 3; ++i) acc += static_cast<long double>(J[6 * i + a]) * J[6 * i + b];
+      ne->H[6 * a + b] += acc;
+    }
+    long double acc = 0;
+    for (int i = 0; i < 3; ++i) acc += static_cast<long double>(J[6 * i + a]) * e[i];
+    ne->g[a] += acc;
+  }
+  ne->cost += 0.5L * rho[0];
+  ne->sum_w += rho[1];
+  ne->n_out += (delta > 0.0 && s > delta * delta) ? 1.0L : 0.0L;
+}
+
+struct EvalOut { double H[36], g[6], cost, sum_w, n_out; };
+
+void evaluate_all(int mode, int per_match_depth, const double* x1, const double* x2, const double* d12,
+                  size_t n, const double rot[3], const double tran[3], double d1, double d2, double delta,
+                  int threads, EvalOut* out) {
+  NormalEq total;
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_num_procs();
+#else
+  threads = 1;
+#endif
+  std::vector<NormalEq> part(static_cast<size_t>(threads));
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int t = 0; t < threads; ++t) {
+    const size_t lo = n * static_cast<size_t>(t) / threads, hi = n * static_cast<size_t>(t + 1) / threads;
+    NormalEq local;
+    for (size_t i = lo; i < hi; ++i) {
+      const double a = per_match_depth ? d12[2 * i] : d1, b = per_match_depth ? d12[2 * i + 1] : d2;
+      accumulate_block(mode, x1 + 3 * i, x2 + 3 * i, rot, tran, a, b, delta, &local);
+    }
+    part[static_cast<size_t>(t)] = local;
+  }
+  for (int t = 0; t < threads; ++t) total.add(part[static_cast<size_t>(t)]);
+  for (int i = 0; i < 36; ++i) out->H[i] = static_cast<double>(total.H[i]);
+  for (int i = 0; i < 6; ++i) out->g[i] = static_cast<double>(total.g[i]);
+  out->cost = static_cast<double>(total.cost);
+  out->sum_w = static_cast<double>(total.sum_w);
+  out->n_out = static_cast<double>(total.n_out);
+}
+
+// "Optimised CPU" baseline (BASELINE.md variant B): rotation and its derivative matrices hoisted out
+// of the loop (central differences are NOT used: the matrices come from dual numbers once), analytic
+// per-match arithmetic in plain double, OpenMP reduction.  Timed next to the faithful loop so the
+// GPU speed-up is not quoted against per-match trig alone.
+void evaluate_all_hoisted(int mode, int per_match_depth, const double* x1, const double* x2,
+                          const double* d12, size_t n, const double rot[3], const double tran[3],
+                          double d1u, double d2u, double delta, int threads, EvalOut* out) {
+  // R and G_j = dR/dw_j from the dual-number rotation applied to the basis vectors
+  double R[9], G[27];
+  {
+    typedef Dual<3> T;
+    T w[3] = {T::var(rot[0], 0), T::var(rot[1], 1), T::var(rot[2], 2)};
+    for (int c = 0; c < 3; ++c) {
+      T p[3] = {T(c == 0 ? 1.0 : 0.0), T(c == 1 ? 1.0 : 0.0), T(c == 2 ? 1.0 : 0.0)}, q[3];
+      angle_axis_rotate(w, p, q);
+      for (int r = 0; r < 3; ++r) { R[3 * r + c] = q[r].v; for (int j = 0; j < 3; ++j) G[9 * j + 3 * r + c] = q[r].d[j]; }
+    }
+  }
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_num_procs();
+#else
+  threads = 1;
+#endif
+  const bool rot_free = mode != MODE_TRAN, tran_free = mode != MODE_ROT;
+  std::vector<EvalOut> part(static_cast<size_t>(threads));
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int t = 0; t < threads; ++t) {
+    const size_t lo = n * static_cast<size_t>(t) / threads, hi = n * static_cast<size_t>(t + 1) / threads;
+    EvalOut acc;
+    std::memset(&acc, 0, sizeof(acc));
+    for (size_t i = lo; i < hi; ++i) {
+      const double* p = x1 + 3 * i;
+      const double* q = x2 + 3 * i;
+      const double d1 = per_match_depth ? d12[2 * i] : d1u, d2 = per_match_depth ? d12[2 * i + 1] : d2u;
+      double e[3], J[18] = {0};
+      for (int r = 0; r < 3; ++r) {
+        const double rx = R[3 * r] * p[0] + R[3 * r + 1] * p[1] + R[3 * r + 2] * p[2];
+        e[r] = d2 * q[r] - (d1 * rx - tran[r]);
+        if (rot_free)
+          for (int j = 0; j < 3; ++j)
+            J[6 * r + j] = -d1 * (G[9 * j + 3 * r] * p[0] + G[9 * j + 3 * r + 1] * p[1] + G[9 * j + 3 * r + 2] * p[2]);
+        if (tran_free) J[6 * r + 3 + r] = 1.0;
+      }
+      const double s = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+      double rho[3] = {s, 1.0, 0.0};
+      if (delta > 0.0) huber_evaluate(delta, s, rho);
+      const double w = rho[1];
+      for (int a = 0; a < 6; ++a) {
+        for (int b = a; b < 6; ++b)
+          acc.H[6 * a + b] += w * (J[a] * J[b] + J[6 + a] * J[6 + b] + J[12 + a] * J[12 + b]);
+        acc.g[a] += w * (J[a] * e[0] + J[6 + a] * e[1] + J[12 + a] * e[2]);
+      }
+      acc.cost += 0.5 * rho[0];
+      acc.sum_w += w;
+      acc.n_out += (delta > 0.0 && s > delta * delta) ? 1.0 : 0.0;
+    }
+    part[static_cast<size_t>(t)] = acc;
+  }
+  std::memset(out, 0, sizeof(*out));
+  for (int t = 0; t < threads; ++t) {
+    const EvalOut& a = part[static_cast<size_t>(t)];
+    for (int i = 0; i < 36; ++i) out->H[i] += a.H[i];
+    for (int i = 0; i < 6; ++i) out->g[i] += a.g[i];
+    out->cost += a.cost; out->sum_w += a.sum_w; out->n_out += a.n_out;
+  }
+  for (int a = 0; a < 6; ++a) for (int b = 0; b < a; ++b) out->H[6 * a + b] = out->H[6 * b + a];
+}
+
+// ---- dense helpers for the minimiser restatement ----------------------------------------------------
+bool spd_solve(int m, const double* A, const double* b, double* x) {
+  std::vector<double> L(static_cast<size_t>(m) * m, 0.0), z(static_cast<size_t>(m));
+  for (int j = 0; j < m; ++j) {
+    double dj = A[j * m + j];
+    for (int k = 0; k < j; ++k) dj -= L[j * m + k] * L[j * m + k];
+    if (!(dj > 0.0) || !std::isfinite(dj)) return false;
+    L[j * m + j] = std::sqrt(dj);
+    for (int i = j + 1; i < m; ++i) {
+      double v = A[i * m + j];
+      for (int k = 0; k < j; ++k) v -= L[i * m + k] * L[j * m + k];
+      L[i * m + j] = v / L[j * m + j];
+    }
+  }
+  for (int i = 0; i < m; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[i * m + k] * z[k]; z[i] = v / L[i * m + i]; }
+  for (int i = m - 1; i >= 0; --i) { double v = z[i]; for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * x[k]; x[i] = v / L[i * m + i]; }
+  return true;
+}
+
+struct LmOptions {   // mirrors the fields of sba_lm_options that the tests set (same order)
+  int max_num_iterations;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  int jacobi_scaling;
+  double huber_delta;
+  int tran_param;
+  int verbose;
+};
+struct LmSummary { int termination, num_iterations, num_successful_steps, num_evaluations; double initial_cost, final_cost, final_gradient_max_norm, final_radius; };
+
+void perp_basis(const double t[3], double b0[3], double b1[3]) {
+  const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+  double u[3] = {1, 0, 0};
+  if (n > 0) for (int i = 0; i < 3; ++i) u[i] = t[i] / n;
+  int k = 0;
+  if (std::fabs(u[1]) < std::fabs(u[k])) k = 1;
+  if (std::fabs(u[2]) < std::fabs(u[k])) k = 2;
+  double a[3] = {0, 0, 0}; a[k] = 1;
+  b0[0] = u[1] * a[2] - u[2] * a[1]; b0[1] = u[2] * a[0] - u[0] * a[2]; b0[2] = u[0] * a[1] - u[1] * a[0];
+  const double n0 = std::sqrt(b0[0] * b0[0] + b0[1] * b0[1] + b0[2] * b0[2]);
+  for (int i = 0; i < 3; ++i) b0[i] /= n0;
+  b1[0] = u[1] * b0[2] - u[2] * b0[1]; b1[1] = u[2] * b0[0] - u[0] * b0[2]; b1[2] = u[0] * b0[1] - u[1] * b0[0];
+}
+
+}  // namespace
+
+// ==================================================================================================
+extern "C" {
+
+int orc_num_procs(void) {
+#ifdef _OPENMP
+  return omp_get_num_procs();
+#else
+  return 1;
+#endif
+}
+
+// Single residual block: e[3], J[3][6] (row-major) -- golden point-wise vectors.
+void orc_point(int mode, const double* cam1, const double* cam2, const double* rot, const double* tran,
+               double d1, double d2, double* e, double* J) {
+  point_residual_jacobian(mode, cam1, cam2, rot, tran, d1, d2, e, J);
+}
+
+void orc_huber(double a, double s, double* rho) { huber_evaluate(a, s, rho); }
+
+void orc_rotate(const double* w, const double* p, double* out) { angle_axis_rotate<double>(w, p, out); }
+
+// out: H[36] g[6] cost sum_w n_out  (45 doubles)
+void orc_eval(int mode, int per_match_depth, const double* x1, const double* x2, const double* d12,
+              size_t n, const double* rot, const double* tran, double d1, double d2, double delta,
+              int threads, double* out45) {
+  EvalOut o;
+  evaluate_all(mode, per_match_depth, x1, x2, d12, n, rot, tran, d1, d2, delta, threads, &o);
+  std::memcpy(out45, &o, sizeof(o));
+}
+
+void orc_eval_hoisted(int mode, int per_match_depth, const double* x1, const double* x2, const double* d12,
+                      size_t n, const double* rot, const double* tran, double d1, double d2, double delta,
+                      int threads, double* out45) {
+  EvalOut o;
+  evaluate_all_hoisted(mode, per_match_depth, x1, x2, d12, n, rot, tran, d1, d2, delta, threads, &o);
+  std::memcpy(out45, &o, sizeof(o));
+}
+
+// Restatement of Ceres' default trust-region Levenberg-Marquardt loop (what ceres::Solve runs for the
+// reference with the options of spherical_bundle_adjuster.cpp:334-338), on the dense normal equations.
+// `faithful` = 1 evaluates with the dual-number loop, 0 with the hoisted loop.
+int orc_lm_solve(int mode, int per_match_depth, const double* x1, const double* x2, const double* d12,
+                 size_t n, double* rot, double* tran, double d1, double d2, const LmOptions* opt,
+                 int threads, int faithful, LmSummary* sum) {
+  const LmOptions& o = *opt;
+  std::memset(sum, 0, sizeof(*sum));
+  auto evaluate = [&](const double* r, const double* t, EvalOut* e) {
+    if (faithful) evaluate_all(mode, per_match_depth, x1, x2, d12, n, r, t, d1, d2, o.huber_delta, threads, e);
+    else evaluate_all_hoisted(mode, per_match_depth, x1, x2, d12, n, r, t, d1, d2, o.huber_delta, threads, e);
+    sum->num_evaluations++;
+  };
+  const bool rot_free = mode != MODE_TRAN, tran_free = mode != MODE_ROT;
+  const bool sphere = tran_free && o.tran_param == 1;
+  const int m = (rot_free ? 3 : 0) + (tran_free ? (sphere ? 2 : 3) : 0);
+  double tnorm = std::sqrt(tran[0] * tran[0] + tran[1] * tran[1] + tran[2] * tran[2]);
+
+  // local Jacobian of Plus at x: columns of P (6 x m)
+  std::vector<double> P(6 * static_cast<size_t>(m));
+  auto build_P = [&](const double* t) {
+    std::fill(P.begin(), P.end(), 0.0);
+    int c = 0;
+    if (rot_free) { for (int a = 0; a < 3; ++a) P[a * m + c + a] = 1; c += 3; }
+    if (tran_free) {
+      if (sphere) {
+        double b0[3], b1[3];
+        perp_basis(t, b0, b1);
+        for (int r = 0; r < 3; ++r) { P[(3 + r) * m + c] = b0[r]; P[(3 + r) * m + c + 1] = b1[r]; }
+      } else {
+        for (int a = 0; a < 3; ++a) P[(3 + a) * m + c + a] = 1;
+      }
+    }
+  };
+  std::vector<double> H(static_cast<size_t>(m) * m), g(static_cast<size_t>(m)), scale(static_cast<size_t>(m)), diag(static_cast<size_t>(m));
+  auto reduce = [&](const EvalOut& e) {
+    for (int i = 0; i < m; ++i) {
+      for (int j = 0; j < m; ++j) {
+        double s = 0;
+        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) s += P[a * m + i] * e.H[6 * a + b] * P[b * m + j];
+        H[i * m + j] = s;
+      }
+      double s = 0;
+      for (int a = 0; a < 6; ++a) s += P[a * m + i] * e.g[a];
+      g[i] = s;
+    }
+  };
+  auto max_abs = [&](const std::vector<double>& v) { double r = 0; for (double x : v) r = std::max(r, std::fabs(x)); return r; };
+
+  EvalOut cur;
+  evaluate(rot, tran, &cur);
+  sum->initial_cost = cur.cost;
+  build_P(tran);
+  reduce(cur);
+  for (int i = 0; i < m; ++i) scale[i] = o.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(std::max(H[i * m + i], 0.0))) : 1.0;
+  double gmax = max_abs(g), radius = o.initial_trust_region_radius, nu = 2.0;
+  bool reuse_diag = false;
+  int invalid = 0;
+  auto done = [&](int term) { sum->termination = term; sum->final_cost = cur.cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius; return 0; };
+  if (gmax <= o.gradient_tolerance) return done(2);
+
+  for (int it = 1;; ++it) {
+    if (it > o.max_num_iterations) return done(4);
+    if (radius < o.min_trust_region_radius) return done(5);
+    sum->num_iterations = it;
+    std::vector<double> Hs(static_cast<size_t>(m) * m), gs(static_cast<size_t>(m)), A, rhs(static_cast<size_t>(m)), y(static_cast<size_t>(m));
+    for (int i = 0; i < m; ++i) { gs[i] = scale[i] * g[i]; for (int j = 0; j < m; ++j) Hs[i * m + j] = scale[i] * H[i * m + j] * scale[j]; }
+    if (!reuse_diag) for (int i = 0; i < m; ++i) diag[i] = std::min(std::max(Hs[i * m + i], o.min_lm_diagonal), o.max_lm_diagonal);
+    A = Hs;
+    for (int i = 0; i < m; ++i) { A[i * m + i] += diag[i] / radius; rhs[i] = -gs[i]; }
+    bool ok = spd_solve(m, A.data(), rhs.data(), y.data());
+    double model = 0;
+    if (ok) {
+      for (int i = 0; i < m; ++i) { double Hy = 0; for (int j = 0; j < m; ++j) Hy += Hs[i * m + j] * y[j]; model -= y[i] * (gs[i] + 0.5 * Hy); }
+      ok = model > 0.0;
+    }
+    if (!ok) { if (++invalid >= 5) { done(6); return -6; } radius /= nu; nu *= 2; reuse_diag = true; continue; }
+    invalid = 0;
+    double step6[6] = {0};
+    for (int a = 0; a < 6; ++a) for (int i = 0; i < m; ++i) step6[a] += P[a * m + i] * scale[i] * y[i];
+    double rc[3], tc[3];
+    for (int a = 0; a < 3; ++a) { rc[a] = rot[a] + step6[a]; tc[a] = tran[a] + step6[3 + a]; }
+    if (sphere) { const double nn = std::sqrt(tc[0] * tc[0] + tc[1] * tc[1] + tc[2] * tc[2]); if (nn > 0) for (int a = 0; a < 3; ++a) tc[a] *= tnorm / nn; }
+    EvalOut cand;
+    evaluate(rc, tc, &cand);
+    double step2 = 0, x2n = 0;
+    for (int a = 0; a < 3; ++a) {
+      if (rot_free) { step2 += (rc[a] - rot[a]) * (rc[a] - rot[a]); x2n += rot[a] * rot[a]; }
+      if (tran_free) { step2 += (tc[a] - tran[a]) * (tc[a] - tran[a]); x2n += tran[a] * tran[a]; }
+    }
+    if (std::sqrt(step2) <= o.parameter_tolerance * (std::sqrt(x2n) + o.parameter_tolerance)) return done(3);
+    const double change = cur.cost - cand.cost;
+    if (std::isfinite(cand.cost) && std::fabs(change) <= o.function_tolerance * cur.cost) return done(1);
+    const double quality = std::isfinite(cand.cost) ? change / model : -1.0;
+    if (quality > o.min_relative_decrease) {
+      for (int a = 0; a < 3; ++a) { rot[a] = rc[a]; tran[a] = tc[a]; }
+      cur = cand;
+      sum->num_successful_steps++;
+      build_P(tran);
+      reduce(cur);
+      gmax = max_abs(g);
+      const double q = 2.0 * quality - 1.0;
+      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
+      nu = 2.0; reuse_diag = false;
+      if (gmax <= o.gradient_tolerance) return done(2);
+    } else {
+      radius /= nu; nu *= 2; reuse_diag = true;
+    }
+  }
+}
+
+// ---- pixel -> unit sphere, spherical_bundle_adjuster.cpp:271-298 -------------------------------------
+void orc_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride, int im_w, int im_h, double* out) {
+  const double w = im_w, h = im_h;
+  for (size_t i = 0; i < n; ++i) {
+    float px, py;
+    std::memcpy(&px, kp + i * stride, 4);
+    std::memcpy(&py, kp + i * stride + 4, 4);
+    const double lon = 2 * M_PI * (px / w);      // .cpp:279
+    const double colat = M_PI * (py / h);        // .cpp:281
+    out[3 * i + 0] = std::sin(colat) * std::cos(lon);   // .cpp:291-293
+    out[3 * i + 1] = std::sin(colat) * std::sin(lon);
+    out[3 * i + 2] = std::cos(colat);
+  }
+}
+
+// ---- ERP -> cubemap strip, equi2cube.cpp:12-302 -----------------------------------------------------
+// face order of get_all (equi2cube.cpp:292-298): left, front, right, back, top, bottom.  `clamp` != 0
+// clamps the source index into the image (the reference does not, equi2cube.cpp:47-50); the number of
+// pixels where clamping changed anything is returned.
+long orc_equi2cube(const uint8_t* im, int im_h, int im_w, int S, int clamp, uint8_t* out) {
+  long clamped = 0;
+  for (int face = 0; face < 6; ++face)
+    for (int i = 0; i < S; ++i)
+      for (int j = 0; j < S; ++j) {
+        double v[3];
+        switch (face) {
+          case 0: v[0] = (S - 2.0 * j) / S; v[1] = 1.0; v[2] = (S - 2.0 * i) / S; break;           // left   :118-120
+          case 1: v[0] = -1.0; v[1] = (S - 2.0 * j) / S; v[2] = (S - 2.0 * i) / S; break;          // front  :73-75
+          case 2: v[0] = (2.0 * j - S) / S; v[1] = -1.0; v[2] = (S - 2.0 * i) / S; break;          // right  :163-165
+          case 3: v[0] = 1.0; v[1] = (2.0 * j - S) / S; v[2] = (S - 2.0 * i) / S; break;           // back   :28-30
+          case 4: v[0] = (S - 2.0 * i) / S; v[1] = (S - 2.0 * j) / S; v[2] = 1.0; break;           // top    :208-210
+          default: v[0] = (2.0 * i - S) / S; v[1] = (S - 2.0 * j) / S; v[2] = -1.0; break;         // bottom :253-255
+        }
+        const double nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const double ux = v[0] / nrm, uy = v[1] / nrm, uz = v[2] / nrm;
+        const double theta = std::acos(uz);
+        double phi = std::atan2(uy, ux);
+        if (phi < 0) phi += M_PI * 2;
+        int row = static_cast<int>(im_h * theta / M_PI);
+        int col = static_cast<int>(im_w * phi / (2 * M_PI));
+        if (row < 0 || row >= im_h || col < 0 || col >= im_w) {
+          ++clamped;
+          if (clamp) { row = std::min(std::max(row, 0), im_h - 1); col = std::min(std::max(col, 0), im_w - 1); }
+          else { continue; }
+        }
+        const uint8_t* s = im + (static_cast<size_t>(row) * im_w + col) * 3;
+        uint8_t* d = out + (static_cast<size_t>(i) * 6 * S + static_cast<size_t>(face) * S + j) * 3;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+      }
+  return clamped;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""Host-side Python mirror of the C-ABI (thin; the C++ mirror of the reference class lives in
+``csrc/spherical_bundle_adjuster.hpp``).  Names follow the reference's domain: a *problem* holds
+one shard of *correspondences* (matched key-points as unit vectors), a *sweep* is one residual +
+Jacobian evaluation over them, the *solve stage* is the LM loop of ``solve_problem``
+(reference spherical_bundle_adjuster.cpp:183-217)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _cabi as cabi
+from ._cabi import (DEPTH_PER_MATCH, DEPTH_UNIFORM, MODE_ROT, MODE_RT, MODE_TRAN, STORE_F32,  # noqa: F401
+                    STORE_F64, TRAN_FREE, TRAN_SPHERE, SbaError)
+
+
+@dataclass
+class NormalEquations:
+    H: np.ndarray          # (6, 6) sum rho' J^T J over [rot | tran]
+    g: np.ndarray          # (6,)   sum rho' J^T e
+    cost: float            # 1/2 sum rho
+    sum_w: float
+    n_outlier: float
+
+
+@dataclass
+class SolveSummary:
+    termination: str
+    num_iterations: int
+    num_successful_steps: int
+    num_evaluations: int
+    initial_cost: float
+    final_cost: float
+    final_gradient_max_norm: float
+    final_radius: float
+    seconds_total: float
+    seconds_eval: float
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def device_count() -> int:
+    lib = cabi.load_library()
+    n = C.c_int(0)
+    cabi.check(lib, lib.sba_device_count(C.byref(n)))
+    return n.value
+
+
+def default_lm_options(**overrides) -> cabi.LmOptions:
+    lib = cabi.load_library()
+    o = cabi.LmOptions()
+    lib.sba_lm_options_default(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def expand_pack(mode: int, pack) -> NormalEquations:
+    lib = cabi.load_library()
+    pack = _f64(pack, (cabi.PACK_SIZE,))
+    ne = cabi.NormalEq()
+    cabi.check(lib, lib.sba_expand_pack(mode, _dptr(pack), C.byref(ne)))
+    return _to_ne(ne)
+
+
+def _to_ne(ne: cabi.NormalEq) -> NormalEquations:
+    return NormalEquations(np.array(ne.H, dtype=np.float64).reshape(6, 6), np.array(ne.g, dtype=np.float64),
+                           float(ne.cost), float(ne.sum_w), float(ne.n_outlier))
+
+
+class Problem:
+    """One shard of correspondences resident on one GPU (``sba_problem``)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = cabi.load_library()
+        self._h = C.c_void_p()
+        cabi.check(self._lib, self._lib.sba_problem_create(C.byref(self._h), device, C.c_void_p(stream or 0)))
+        self._hook_keepalive = None
+        self.device = device
+
+    # -- life cycle ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sba_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ------------------------------------------------------------------------------------
+    def upload(self, left_xyz, right_xyz, d12=None, store: int = STORE_F64) -> None:
+        """left_xyz/right_xyz: (n,3) f64 unit vectors (cv::Point3d layout); d12: (n,2) or None."""
+        x1 = _f64(left_xyz).reshape(-1, 3)
+        x2 = _f64(right_xyz).reshape(-1, 3)
+        if x1.shape != x2.shape:
+            raise ValueError("left/right shapes differ")
+        n = x1.shape[0]
+        dp = None
+        if d12 is not None:
+            d = _f64(d12).reshape(-1, 2)
+            if d.shape[0] != n:
+                raise ValueError("d12 length differs")
+            dp = d.ctypes.data_as(C.c_void_p)
+        cabi.check(self._lib, self._lib.sba_problem_upload(
+            self._h, x1.ctypes.data_as(C.c_void_p), x2.ctypes.data_as(C.c_void_p), dp, n, store))
+
+    def upload_device(self, left_ptr: int, right_ptr: int, d12_ptr: int | None, n: int,
+                      store: int = STORE_F64) -> None:
+        cabi.check(self._lib, self._lib.sba_problem_upload_device(
+            self._h, C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_void_p(d12_ptr or 0), n, store))
+
+    @property
+    def size(self) -> int:
+        n = C.c_size_t(0)
+        cabi.check(self._lib, self._lib.sba_problem_size(self._h, C.byref(n)))
+        return n.value
+
+    # -- sweeps -----------------------------------------------------------------------------------
+    def eval(self, mode, rot, tran, d1=1.0, d2=1.0, huber_delta=1.0, depth_mode=DEPTH_UNIFORM) -> NormalEquations:
+        rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
+        ne = cabi.NormalEq()
+        cabi.check(self._lib, self._lib.sba_problem_eval(self._h, mode, depth_mode, _dptr(rot), _dptr(tran),
+                                                         d1, d2, huber_delta, C.byref(ne)))
+        return _to_ne(ne)
+
+    def eval_pack(self, mode, rot, tran, d1=1.0, d2=1.0, huber_delta=1.0, depth_mode=DEPTH_UNIFORM) -> np.ndarray:
+        rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
+        pack = np.zeros(cabi.PACK_SIZE)
+        cabi.check(self._lib, self._lib.sba_problem_eval_pack(self._h, mode, depth_mode, _dptr(rot), _dptr(tran),
+                                                              d1, d2, huber_delta, _dptr(pack)))
+        return pack
+
+    def eval_timed(self, mode, rot, tran, d1=1.0, d2=1.0, huber_delta=1.0, depth_mode=DEPTH_UNIFORM,
+                   repeat: int = 10):
+        """`repeat` back-to-back sweeps timed with HIP events on the problem's stream.
+        Returns (pack, mean ms per step [sweep+finalize(+all-reduce)], mean ms of the sweep kernel alone)."""
+        rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
+        pack = np.zeros(cabi.PACK_SIZE)
+        step_ms, sweep_ms = C.c_double(0), C.c_double(0)
+        cabi.check(self._lib, self._lib.sba_problem_eval_timed(self._h, mode, depth_mode, _dptr(rot), _dptr(tran),
+                                                               d1, d2, huber_delta, repeat, _dptr(pack),
+                                                               C.byref(step_ms), C.byref(sweep_ms)))
+        return pack, step_ms.value, sweep_ms.value
+
+    # -- solve stage --------------------------------------------------------------------------------
+    def solve(self, mode, rot, tran, d1=1.0, d2=1.0, depth_mode=DEPTH_UNIFORM, options: cabi.LmOptions | None = None):
+        """LM solve; returns (rot, tran, SolveSummary).  Inputs are not modified."""
+        rot = _f64(rot, (3,)).copy()
+        tran = _f64(tran, (3,)).copy()
+        opt = options if options is not None else default_lm_options()
+        s = cabi.LmSummary()
+        cabi.check(self._lib, self._lib.sba_problem_solve(self._h, mode, depth_mode, _dptr(rot), _dptr(tran),
+                                                          d1, d2, C.byref(opt), C.byref(s)))
+        return rot, tran, SolveSummary(cabi.TERMINATION.get(s.termination, str(s.termination)), s.num_iterations,
+                                       s.num_successful_steps, s.num_evaluations, s.initial_cost, s.final_cost,
+                                       s.final_gradient_max_norm, s.final_radius, s.seconds_total, s.seconds_eval)
+
+    def solve_depths(self, rot, tran, lam=1.0, c=1.0, max_iterations=50):
+        rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
+        out = np.zeros((self.size, 2))
+        cost = C.c_double(0)
+        cabi.check(self._lib, self._lib.sba_problem_solve_depths(self._h, _dptr(rot), _dptr(tran), lam, c,
+                                                                 max_iterations, out.ctypes.data_as(C.c_void_p),
+                                                                 C.byref(cost)))
+        return out, cost.value
+
+    # -- multi-GPU ------------------------------------------------------------------------------------
+    def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes) -> None:
+        if len(unique_id) != cabi.COMM_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        cabi.check(self._lib, self._lib.sba_problem_comm_init_rank(self._h, nranks, rank, unique_id))
+
+    def set_allreduce(self, fn) -> None:
+        """fn(device_ptr: int, count: int, stream: int) -> int (0 = ok), or None to clear."""
+        if fn is None:
+            cb = C.cast(None, cabi.ALLREDUCE_FN)
+        else:
+            def _tramp(buf, count, stream, _user):
+                try:
+                    return int(fn(buf or 0, count, stream or 0) or 0)
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            cb = cabi.ALLREDUCE_FN(_tramp)
+        self._hook_keepalive = cb
+        cabi.check(self._lib, self._lib.sba_problem_set_allreduce(self._h, cb, None))
+
+    @property
+    def pack_device_ptr(self) -> int:
+        p = C.c_void_p()
+        cabi.check(self._lib, self._lib.sba_problem_pack_device_ptr(self._h, C.byref(p)))
+        return p.value or 0
+
+
+def comm_unique_id() -> bytes:
+    lib = cabi.load_library()
+    buf = C.create_string_buffer(cabi.COMM_ID_BYTES)
+    cabi.check(lib, lib.sba_comm_unique_id(buf))
+    return buf.raw
+
+
+def keypoints_to_sphere(keypoints: np.ndarray, im_width: int, im_height: int, device: int = 0) -> np.ndarray:
+    """keypoints: structured/2-D array whose rows start with float32 pt.x, pt.y (cv::KeyPoint: 28 B)."""
+    lib = cabi.load_library()
+    kp = np.ascontiguousarray(keypoints)
+    n = kp.shape[0]
+    stride = kp.strides[0] if n > 0 else 28
+    out = np.zeros((n, 3))
+    cabi.check(lib, lib.sba_keypoints_to_sphere(device, kp.ctypes.data_as(C.c_void_p), n, stride, im_width,
+                                                im_height, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def equi2cube(erp: np.ndarray, cube_size: int, device: int = 0) -> np.ndarray:
+    """erp: (H, W, 3) uint8 -> (S, 6S, 3) uint8 strip, faces left,front,right,back,top,bottom."""
+    lib = cabi.load_library()
+    im = np.ascontiguousarray(erp, dtype=np.uint8)
+    if im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError("erp must be (H, W, 3) uint8")
+    out = np.zeros((cube_size, 6 * cube_size, 3), dtype=np.uint8)
+    cabi.check(lib, lib.sba_equi2cube(device, im.ctypes.data_as(C.c_void_p), im.shape[0], im.shape[1], cube_size,
+                                      out.ctypes.data_as(C.c_void_p)))
+    return out

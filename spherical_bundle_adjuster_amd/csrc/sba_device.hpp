@@ -1,0 +1,74 @@
+// Internal interface between the C-ABI shim (sba_shim.cpp) and the HIP kernels
+// (sba_kernels.hip).  Nothing here is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace sba {
+
+// Wave-uniform state of one sweep, passed BY VALUE as a kernel argument (kernarg segment ->
+// scalar loads), staged in LDS by the kernel prologue.
+//   uniform depths  : Rn = -d1 * R,  Gn_j = -d1 * dR/dw_j   (d1 folded in on the host)
+//   per-match depths: Rn = -R,       Gn_j = -dR/dw_j        (d1_i applied per match)
+// so that  e = t + d2 x2 + [d1_i] Rn x1   and   A = d(e)/d(rot) = [d1_i] [Gn_0 x1 | Gn_1 x1 | Gn_2 x1].
+struct SweepParams {
+  double Rn[9];
+  double Gn[27];   // Gn[9*j + 3*r + c]
+  double t[3];
+  double d2;       // uniform depth of the right point (unused with per-match depths)
+  double delta;    // Huber a; <= 0: no robustifier
+  double delta2;   // a*a
+  unsigned long long n;  // correspondences in this shard
+};
+static_assert(sizeof(SweepParams) == 43 * 8, "SweepParams layout");
+
+// Device-resident correspondences as planes (structure of arrays): every lane of a wave reads
+// 16 consecutive bytes of one plane, so each wave load instruction covers 1 KiB contiguous.
+struct Planes {
+  const void* x1[3];  // left unit vectors  x, y, z   (double or float per `store`)
+  const void* x2[3];  // right unit vectors x, y, z
+  const double* d1;   // per-match depths (always f64), may be null
+  const double* d2;
+};
+
+constexpr int kPackSize = 24;
+constexpr int kBlock = 256;
+
+// Sweep: residual + Jacobian + Huber + reduction of every block's partial pack into
+// partials[grid][24]; then finalize() folds the partials in a fixed order into pack_out[24].
+hipError_t launch_sweep(int mode, int depth, int store, const Planes& pl, const SweepParams& prm,
+                        double* partials, int grid, hipStream_t stream);
+hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream);
+
+// AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.
+hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void* px, void* py,
+                                void* pz, int store, hipStream_t stream);
+// d12 (double[2n]) -> two f64 planes.
+hipError_t launch_d12_to_planes(const double* d12, size_t n, size_t first, double* d1, double* d2,
+                                hipStream_t stream);
+hipError_t launch_planes_to_d12(const double* d1, const double* d2, size_t n, double* d12,
+                                hipStream_t stream);
+
+// d-only stage: per match bounded 2-parameter LM (spherical_bundle_adjuster.cpp:1004-1063).
+struct DepthParams {
+  double R[9];
+  double t[3];
+  double lambda, c;
+  int max_iterations;
+  unsigned long long n;
+};
+hipError_t launch_depth_solve(int store, const Planes& pl, double* d1, double* d2,
+                              const DepthParams& prm, double* cost_partials, int grid,
+                              hipStream_t stream);
+
+// pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
+hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride_bytes, double im_w,
+                                      double im_h, double* out_xyz, hipStream_t stream);
+// ERP -> cubemap strip (equi2cube.cpp:12-302)
+hipError_t launch_equi2cube(const uint8_t* erp, int im_h, int im_w, int cube, int batch, uint8_t* out,
+                            hipStream_t stream);
+
+int points_per_lane(int store);  // 2 for f64 planes, 4 for f32 planes
+
+}  // namespace sba

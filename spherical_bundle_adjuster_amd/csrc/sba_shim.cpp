@@ -1,0 +1,599 @@
+// C-ABI shim (include/sba_hip.h) over the HIP kernels: handles, uploads, sweeps, RCCL.
+// Host code only; compiled with hipcc for the HIP runtime API.  No CPU fallback exists here:
+// every compute entry point needs a HIP device and fails with SBA_ERR_NO_DEVICE otherwise.
+#include "../../include/sba_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sba_device.hpp"
+#include "sba_lm.hpp"
+#include "sba_rotation.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define SBA_HIP_TRY(expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(SBA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                \
+  } while (0)
+
+// ---- RCCL, bound at run time -------------------------------------------------------------------
+// The library is dlopen'ed instead of linked so that a process which already carries an RCCL
+// (torch ships its own librccl.so.1) keeps exactly one copy.
+struct Rccl {
+  typedef struct { char internal[SBA_COMM_ID_BYTES]; } UniqueId;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* handle = nullptr;
+  bool ok = false;
+  std::string why;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    r.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    if (r.handle) break;
+  }
+  if (!r.handle)
+    for (const char* nm : names) {
+      r.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+      if (r.handle) break;
+    }
+  if (!r.handle) {
+    r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+    return r;
+  }
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
+  r.GetErrorString =
+      reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
+  if (!r.ok) r.why = "librccl is missing ncclGetUniqueId/CommInitRank/CommDestroy/AllReduce";
+  return r;
+}
+constexpr int kNcclFloat64 = 8;  // ncclDouble
+constexpr int kNcclSum = 0;      // ncclSum
+
+}  // namespace
+
+// ---- the handle ---------------------------------------------------------------------------------
+struct sba_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 0;
+  int blocks_per_cu = 4;
+
+  size_t n = 0;
+  int store = SBA_STORE_F64;
+  bool has_d12 = false;
+  bool uploaded = false;
+  size_t plane_elems = 0;     // allocated elements per plane (n rounded up to a whole vector)
+  void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* dplane[2] = {nullptr, nullptr};
+
+  double* partials = nullptr;  // [max_grid][24]
+  int max_grid = 0;
+  double* pack_dev = nullptr;  // 32 doubles
+  double* pack_host = nullptr; // pinned, 32 doubles
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> sweep_events;        // eval_timed: brackets of each sweep launch
+  hipEvent_t ev_sweep0 = nullptr, ev_sweep1 = nullptr;
+
+  sba_allreduce_fn hook = nullptr;
+  void* hook_user = nullptr;
+  void* comm = nullptr;        // ncclComm_t
+  int nranks = 1;
+};
+
+namespace {
+
+int free_planes(sba_problem* p) {
+  for (auto& c : p->coord) {
+    if (c) SBA_HIP_TRY(hipFree(c));
+    c = nullptr;
+  }
+  for (auto& d : p->dplane) {
+    if (d) SBA_HIP_TRY(hipFree(d));
+    d = nullptr;
+  }
+  p->uploaded = false;
+  p->n = 0;
+  p->plane_elems = 0;
+  p->has_d12 = false;
+  return SBA_OK;
+}
+
+int alloc_planes(sba_problem* p, size_t n, bool with_d12, int store) {
+  int rc = free_planes(p);
+  if (rc) return rc;
+  const size_t esz = store == SBA_STORE_F64 ? 8 : 4;
+  // whole 16-byte vectors, plus one spare vector so that the ragged tail load stays in bounds
+  const size_t ppt = static_cast<size_t>(sba::points_per_lane(store));
+  const size_t elems = ((n + ppt - 1) / ppt + 1) * ppt;
+  for (auto& c : p->coord) {
+    SBA_HIP_TRY(hipMalloc(&c, elems * esz));
+    SBA_HIP_TRY(hipMemsetAsync(c, 0, elems * esz, p->stream));
+  }
+  if (with_d12)
+    for (auto& d : p->dplane) {
+      SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), elems * 8));
+      SBA_HIP_TRY(hipMemsetAsync(d, 0, elems * 8, p->stream));
+    }
+  p->n = n;
+  p->store = store;
+  p->has_d12 = with_d12;
+  p->plane_elems = elems;
+  return SBA_OK;
+}
+
+int grid_for(const sba_problem* p) {
+  const size_t ppt = static_cast<size_t>(sba::points_per_lane(p->store));
+  const size_t nvec = (p->n + ppt - 1) / ppt;
+  const size_t want = (nvec + sba::kBlock - 1) / sba::kBlock;
+  return static_cast<int>(std::min<size_t>(want, static_cast<size_t>(p->max_grid)));
+}
+
+int check_args(const sba_problem* p, int mode, int depth_mode, const double* rot, const double* tran) {
+  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  if (!rot || !tran) return fail(SBA_ERR_INVALID_ARG, "rot/tran must not be null");
+  if (mode < SBA_MODE_ROT || mode > SBA_MODE_RT) return fail(SBA_ERR_INVALID_ARG, "bad mode %d", mode);
+  if (depth_mode != SBA_DEPTH_UNIFORM && depth_mode != SBA_DEPTH_PER_MATCH)
+    return fail(SBA_ERR_INVALID_ARG, "bad depth_mode %d", depth_mode);
+  if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  if (depth_mode == SBA_DEPTH_PER_MATCH && !p->has_d12 && p->n > 0)
+    return fail(SBA_ERR_INVALID_ARG, "per-match depths requested but none were uploaded");
+  for (int i = 0; i < 3; ++i)
+    if (!std::isfinite(rot[i]) || !std::isfinite(tran[i]))
+      return fail(SBA_ERR_INVALID_ARG, "non-finite rot/tran");
+  return SBA_OK;
+}
+
+void make_params(const sba_problem* p, int depth_mode, const double rot[3], const double tran[3],
+                 double d1, double d2, double huber_delta, sba::SweepParams* prm) {
+  double R[9], G[27];
+  sba::rotation_and_derivatives(rot, R, G);
+  const double scale = depth_mode == SBA_DEPTH_UNIFORM ? -d1 : -1.0;
+  for (int i = 0; i < 9; ++i) prm->Rn[i] = scale * R[i];
+  for (int i = 0; i < 27; ++i) prm->Gn[i] = scale * G[i];
+  for (int i = 0; i < 3; ++i) prm->t[i] = tran[i];
+  prm->d2 = d2;
+  prm->delta = huber_delta > 0.0 ? huber_delta : 0.0;
+  prm->delta2 = prm->delta * prm->delta;
+  prm->n = p->n;
+}
+
+// Enqueue one sweep + finalize (+ all-reduce) on the problem's stream; pack_dev holds the result.
+int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepParams& prm) {
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) {
+    pl.x1[k] = p->coord[k];
+    pl.x2[k] = p->coord[3 + k];
+  }
+  pl.d1 = p->dplane[0];
+  pl.d2 = p->dplane[1];
+  const int grid = grid_for(p);
+  if (p->ev_sweep0) SBA_HIP_TRY(hipEventRecord(p->ev_sweep0, p->stream));
+  SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, pl, prm, p->partials, grid, p->stream));
+  if (p->ev_sweep1) SBA_HIP_TRY(hipEventRecord(p->ev_sweep1, p->stream));
+  SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, p->stream));
+  if (p->comm) {
+    Rccl& r = rccl();
+    const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
+                               p->comm, p->stream);
+    if (rc != 0)
+      return fail(SBA_ERR_COMM, "ncclAllReduce failed: %s",
+                  r.GetErrorString ? r.GetErrorString(rc) : "?");
+  } else if (p->hook) {
+    const int rc = p->hook(p->pack_dev, SBA_PACK_SIZE, p->stream, p->hook_user);
+    if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
+  }
+  return SBA_OK;
+}
+
+int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
+  SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, p->pack_dev, SBA_PACK_SIZE * sizeof(double),
+                             hipMemcpyDeviceToHost, p->stream));
+  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  std::memcpy(pack, p->pack_host, SBA_PACK_SIZE * sizeof(double));
+  return SBA_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int sba_abi_version(void) { return SBA_ABI_VERSION; }
+const char* sba_last_error(void) { return g_last_error.c_str(); }
+
+int sba_device_count(int* count) {
+  if (!count) return fail(SBA_ERR_INVALID_ARG, "count is null");
+  int c = 0;
+  const hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(SBA_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = c;
+  return SBA_OK;
+}
+
+void sba_lm_options_default(sba_lm_options* opt) {
+  if (opt) sba::lm_default_options(opt);
+}
+
+int sba_problem_create(sba_problem** out, int device, void* stream) {
+  if (!out) return fail(SBA_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  int count = 0;
+  const hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(SBA_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= count)
+    return fail(SBA_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, count);
+  SBA_HIP_TRY(hipSetDevice(device));
+  sba_problem* p = new sba_problem();
+  p->device = device;
+  hipDeviceProp_t prop;
+  SBA_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  p->num_cus = prop.multiProcessorCount;
+  if (const char* env = std::getenv("SBA_BLOCKS_PER_CU")) {
+    const int v = std::atoi(env);
+    if (v >= 1 && v <= 32) p->blocks_per_cu = v;
+  }
+  if (stream) {
+    p->stream = static_cast<hipStream_t>(stream);
+  } else {
+    SBA_HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    p->own_stream = true;
+  }
+  p->max_grid = std::max(1, p->num_cus * p->blocks_per_cu);
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->partials),
+                        static_cast<size_t>(p->max_grid) * sba::kPackSize * sizeof(double)));
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->pack_dev), 32 * sizeof(double)));
+  SBA_HIP_TRY(hipMemset(p->pack_dev, 0, 32 * sizeof(double)));
+  SBA_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->pack_host), 32 * sizeof(double),
+                            hipHostMallocDefault));
+  SBA_HIP_TRY(hipEventCreate(&p->ev0));
+  SBA_HIP_TRY(hipEventCreate(&p->ev1));
+  *out = p;
+  return SBA_OK;
+}
+
+int sba_problem_destroy(sba_problem* p) {
+  if (!p) return SBA_OK;
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  if (p->comm) {
+    Rccl& r = rccl();
+    if (r.ok) r.CommDestroy(p->comm);
+  }
+  free_planes(p);
+  if (p->partials) (void)hipFree(p->partials);
+  if (p->pack_dev) (void)hipFree(p->pack_dev);
+  if (p->pack_host) (void)hipHostFree(p->pack_host);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  for (hipEvent_t e : p->sweep_events) (void)hipEventDestroy(e);
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return SBA_OK;
+}
+
+static int upload_common(sba_problem* p, const void* left, const void* right, const void* d12,
+                         size_t n, int store, bool from_device) {
+  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  if (store != SBA_STORE_F64 && store != SBA_STORE_F32)
+    return fail(SBA_ERR_INVALID_ARG, "bad store %d", store);
+  if (n > 0 && (!left || !right)) return fail(SBA_ERR_INVALID_ARG, "null coordinate array");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  int rc = alloc_planes(p, n, d12 != nullptr, store);
+  if (rc) return rc;
+  if (n > 0) {
+    if (from_device) {
+      SBA_HIP_TRY(sba::launch_aos_to_planes(static_cast<const double*>(left), n, 0, p->coord[0],
+                                            p->coord[1], p->coord[2], store, p->stream));
+      SBA_HIP_TRY(sba::launch_aos_to_planes(static_cast<const double*>(right), n, 0, p->coord[3],
+                                            p->coord[4], p->coord[5], store, p->stream));
+      if (d12)
+        SBA_HIP_TRY(sba::launch_d12_to_planes(static_cast<const double*>(d12), n, 0, p->dplane[0],
+                                              p->dplane[1], p->stream));
+    } else {
+      // Bounded staging buffer: chunks of <= 4M correspondences (96 MB) go H2D then are re-laid
+      // out as planes on the device.
+      const size_t chunk = std::min<size_t>(n, size_t(4) << 20);
+      double* stage = nullptr;
+      SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage), chunk * 3 * sizeof(double)));
+      const double* src[2] = {static_cast<const double*>(left), static_cast<const double*>(right)};
+      for (int side = 0; side < 2; ++side)
+        for (size_t first = 0; first < n; first += chunk) {
+          const size_t m = std::min(chunk, n - first);
+          SBA_HIP_TRY(hipMemcpyAsync(stage, src[side] + 3 * first, m * 3 * sizeof(double),
+                                     hipMemcpyHostToDevice, p->stream));
+          SBA_HIP_TRY(sba::launch_aos_to_planes(stage, m, first, p->coord[3 * side + 0],
+                                                p->coord[3 * side + 1], p->coord[3 * side + 2],
+                                                store, p->stream));
+          SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+        }
+      if (d12)
+        for (size_t first = 0; first < n; first += chunk) {
+          const size_t m = std::min(chunk, n - first);
+          SBA_HIP_TRY(hipMemcpyAsync(stage, static_cast<const double*>(d12) + 2 * first,
+                                     m * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+          SBA_HIP_TRY(sba::launch_d12_to_planes(stage, m, first, p->dplane[0], p->dplane[1], p->stream));
+          SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+        }
+      SBA_HIP_TRY(hipFree(stage));
+    }
+  }
+  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  p->uploaded = true;
+  return SBA_OK;
+}
+
+int sba_problem_upload(sba_problem* p, const double* left_xyz, const double* right_xyz,
+                       const double* d12, size_t n, int store) {
+  return upload_common(p, left_xyz, right_xyz, d12, n, store, false);
+}
+
+int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const void* right_xyz_dev,
+                              const void* d12_dev, size_t n, int store) {
+  return upload_common(p, left_xyz_dev, right_xyz_dev, d12_dev, n, store, true);
+}
+
+int sba_problem_size(const sba_problem* p, size_t* n) {
+  if (!p || !n) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  *n = p->n;
+  return SBA_OK;
+}
+
+int sba_problem_eval_pack(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                          const double tran[3], double d1, double d2, double huber_delta,
+                          double pack[SBA_PACK_SIZE]) {
+  int rc = check_args(p, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (!pack) return fail(SBA_ERR_INVALID_ARG, "pack is null");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  sba::SweepParams prm;
+  make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);
+  rc = enqueue_sweep(p, mode, depth_mode, prm);
+  if (rc) return rc;
+  return fetch_pack(p, pack);
+}
+
+int sba_expand_pack(int mode, const double pack[SBA_PACK_SIZE], sba_normal_eq* out) {
+  if (!pack || !out) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (mode < SBA_MODE_ROT || mode > SBA_MODE_RT) return fail(SBA_ERR_INVALID_ARG, "bad mode %d", mode);
+  sba::expand_pack(mode, pack, out);
+  return SBA_OK;
+}
+
+int sba_problem_eval(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                     const double tran[3], double d1, double d2, double huber_delta,
+                     sba_normal_eq* out) {
+  if (!out) return fail(SBA_ERR_INVALID_ARG, "out is null");
+  double pack[SBA_PACK_SIZE];
+  const int rc = sba_problem_eval_pack(p, mode, depth_mode, rot, tran, d1, d2, huber_delta, pack);
+  if (rc) return rc;
+  sba::expand_pack(mode, pack, out);
+  return SBA_OK;
+}
+
+int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                           const double tran[3], double d1, double d2, double huber_delta,
+                           int repeat, double pack[SBA_PACK_SIZE], double* mean_step_ms,
+                           double* mean_sweep_ms) {
+  int rc = check_args(p, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (!pack || repeat < 1 || repeat > 100000) return fail(SBA_ERR_INVALID_ARG, "bad pack/repeat");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  sba::SweepParams prm;
+  make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);
+  while (p->sweep_events.size() < static_cast<size_t>(2 * repeat)) {
+    hipEvent_t e;
+    SBA_HIP_TRY(hipEventCreate(&e));
+    p->sweep_events.push_back(e);
+  }
+  SBA_HIP_TRY(hipEventRecord(p->ev0, p->stream));
+  for (int i = 0; i < repeat; ++i) {
+    p->ev_sweep0 = p->sweep_events[2 * i];
+    p->ev_sweep1 = p->sweep_events[2 * i + 1];
+    rc = enqueue_sweep(p, mode, depth_mode, prm);
+    p->ev_sweep0 = p->ev_sweep1 = nullptr;
+    if (rc) return rc;
+  }
+  SBA_HIP_TRY(hipEventRecord(p->ev1, p->stream));
+  rc = fetch_pack(p, pack);
+  if (rc) return rc;
+  float ms = 0.f;
+  SBA_HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  if (mean_step_ms) *mean_step_ms = static_cast<double>(ms) / repeat;
+  if (mean_sweep_ms) {
+    double tot = 0.0;
+    for (int i = 0; i < repeat; ++i) {
+      SBA_HIP_TRY(hipEventElapsedTime(&ms, p->sweep_events[2 * i], p->sweep_events[2 * i + 1]));
+      tot += ms;
+    }
+    *mean_sweep_ms = tot / repeat;
+  }
+  return SBA_OK;
+}
+
+int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], double tran[3],
+                      double d1, double d2, const sba_lm_options* opt, sba_lm_summary* summary) {
+  int rc = check_args(p, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  sba_lm_options o;
+  if (opt) o = *opt; else sba::lm_default_options(&o);
+  double eval_seconds = 0.0;
+  int eval_rc = SBA_OK;
+  auto evaluator = [&](const double r[3], const double t[3], sba_normal_eq* ne) -> bool {
+    const auto t0 = std::chrono::steady_clock::now();
+    eval_rc = sba_problem_eval(p, mode, depth_mode, r, t, d1, d2, o.huber_delta, ne);
+    eval_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return eval_rc == SBA_OK;
+  };
+  sba_lm_summary local;
+  sba_lm_summary* s = summary ? summary : &local;
+  const int lm_rc = sba::lm_solve(mode, rot, tran, o, evaluator, s);
+  s->seconds_eval = eval_seconds;
+  if (eval_rc != SBA_OK) return eval_rc;  // message already set by the failing eval
+  if (lm_rc != SBA_OK) return fail(lm_rc, "LM failed: non-finite or singular normal equations");
+  return SBA_OK;
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------------
+int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]) {
+  if (!id) return fail(SBA_ERR_INVALID_ARG, "id is null");
+  Rccl& r = rccl();
+  if (!r.ok) return fail(SBA_ERR_COMM, "%s", r.why.c_str());
+  Rccl::UniqueId u;
+  const int rc = r.GetUniqueId(&u);
+  if (rc != 0) return fail(SBA_ERR_COMM, "ncclGetUniqueId failed (%d)", rc);
+  std::memcpy(id, u.internal, SBA_COMM_ID_BYTES);
+  return SBA_OK;
+}
+
+int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]) {
+  if (!p || !id) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SBA_ERR_INVALID_ARG, "bad rank %d/%d", rank, nranks);
+  Rccl& r = rccl();
+  if (!r.ok) return fail(SBA_ERR_COMM, "%s", r.why.c_str());
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  Rccl::UniqueId u;
+  std::memcpy(u.internal, id, SBA_COMM_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, nranks, u, rank);
+  if (rc != 0)
+    return fail(SBA_ERR_COMM, "ncclCommInitRank failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
+  if (p->comm) r.CommDestroy(p->comm);
+  p->comm = comm;
+  p->nranks = nranks;
+  return SBA_OK;
+}
+
+int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user) {
+  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  p->hook = fn;
+  p->hook_user = user;
+  return SBA_OK;
+}
+
+int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr) {
+  if (!p || !dev_ptr) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  *dev_ptr = p->pack_dev;
+  return SBA_OK;
+}
+
+// ---- callers / data formats either side of the path ----------------------------------------------
+int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
+                             double c, int max_iterations, double* d12_out, double* total_cost) {
+  (void)p; (void)rot; (void)tran; (void)lambda; (void)c; (void)max_iterations; (void)d12_out; (void)total_cost;
+  return fail(SBA_ERR_UNSUPPORTED, "sba_problem_solve_depths: d-only stage not built yet");
+}
+
+static int require_device(int device) {
+  int count = 0;
+  const hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(SBA_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= count)
+    return fail(SBA_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, count);
+  SBA_HIP_TRY(hipSetDevice(device));
+  return SBA_OK;
+}
+
+int sba_keypoints_to_sphere(int device, const void* keypoints, size_t n, size_t stride_bytes,
+                            int im_width, int im_height, double* out_xyz) {
+  if (n > 0 && (!keypoints || !out_xyz)) return fail(SBA_ERR_INVALID_ARG, "null array");
+  if (stride_bytes < 8 || stride_bytes % 4 != 0)
+    return fail(SBA_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 8");
+  if (im_width <= 0 || im_height <= 0) return fail(SBA_ERR_INVALID_ARG, "bad image size");
+  int rc = require_device(device);
+  if (rc) return rc;
+  if (n == 0) return SBA_OK;
+  uint8_t* kp_dev = nullptr;
+  double* out_dev = nullptr;
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&kp_dev), n * stride_bytes));
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), n * 3 * sizeof(double)));
+  SBA_HIP_TRY(hipMemcpy(kp_dev, keypoints, n * stride_bytes, hipMemcpyHostToDevice));
+  SBA_HIP_TRY(sba::launch_keypoints_to_sphere(kp_dev, n, stride_bytes, im_width, im_height, out_dev, nullptr));
+  SBA_HIP_TRY(hipMemcpy(out_xyz, out_dev, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  SBA_HIP_TRY(hipFree(kp_dev));
+  SBA_HIP_TRY(hipFree(out_dev));
+  return SBA_OK;
+}
+
+int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
+                         int cube_size, int batch, void* out_dev) {
+  if (!erp_dev || !out_dev) return fail(SBA_ERR_INVALID_ARG, "null image pointer");
+  if (im_height <= 0 || im_width <= 0 || cube_size <= 0 || batch <= 0)
+    return fail(SBA_ERR_INVALID_ARG, "bad image / cube size");
+  if (static_cast<long long>(im_height) * im_width > 0x7fffffffLL / 3)
+    return fail(SBA_ERR_INVALID_ARG, "image too large for 32-bit pixel indices");
+  int rc = require_device(device);
+  if (rc) return rc;
+  SBA_HIP_TRY(sba::launch_equi2cube(static_cast<const uint8_t*>(erp_dev), im_height, im_width, cube_size,
+                                    batch, static_cast<uint8_t*>(out_dev), static_cast<hipStream_t>(stream)));
+  return SBA_OK;
+}
+
+int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, int cube_size,
+                  uint8_t* out) {
+  if (!erp || !out) return fail(SBA_ERR_INVALID_ARG, "null image pointer");
+  if (im_height <= 0 || im_width <= 0 || cube_size <= 0) return fail(SBA_ERR_INVALID_ARG, "bad image / cube size");
+  int rc = require_device(device);
+  if (rc) return rc;
+  const size_t in_bytes = static_cast<size_t>(im_height) * im_width * 3;
+  const size_t out_bytes = static_cast<size_t>(cube_size) * 6 * cube_size * 3;
+  uint8_t *in_dev = nullptr, *out_dev = nullptr;
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&in_dev), in_bytes));
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), out_bytes));
+  SBA_HIP_TRY(hipMemcpy(in_dev, erp, in_bytes, hipMemcpyHostToDevice));
+  rc = sba_equi2cube_device(device, nullptr, in_dev, im_height, im_width, cube_size, 1, out_dev);
+  if (rc) return rc;
+  SBA_HIP_TRY(hipMemcpy(out, out_dev, out_bytes, hipMemcpyDeviceToHost));
+  SBA_HIP_TRY(hipFree(in_dev));
+  SBA_HIP_TRY(hipFree(out_dev));
+  return SBA_OK;
+}
+
+}  // extern "C"

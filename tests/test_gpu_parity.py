@@ -1,0 +1,208 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same seeded inputs,
+against the committed golden fixtures, and through size-independent properties at full size.
+
+Tolerances (helpers.py): normal-equation entries rel 1e-12 (f64 planes) / 5e-6 (f32 planes) of the
+block's largest entry; recovered R|t 1e-9 (f64) / 1e-5 (f32)."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, REL_TOL_F32, REL_TOL_F64, RT_TOL_F32, RT_TOL_F64, assert_normal_eq_close, pack_from_eval
+from spherical_bundle_adjuster_amd import api, synthetic
+
+pytestmark = pytest.mark.gpu
+
+MODES = [api.MODE_ROT, api.MODE_TRAN, api.MODE_RT]
+
+
+@pytest.fixture(scope="module")
+def problem():
+    p = api.Problem(0)
+    yield p
+    p.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 2048, 100003])
+def test_sweep_matches_oracle(problem, oracle, n):
+    c = synthetic.full_rt(n, seed=2000 + n, outlier_fraction=0.1)
+    problem.upload(c.x1, c.x2, c.d12)
+    assert problem.size == n
+    for mode in MODES:
+        for dm, d12 in ((api.DEPTH_UNIFORM, None), (api.DEPTH_PER_MATCH, c.d12)):
+            got = problem.eval(mode, c.rot_init, c.tran_init, 1.3, 0.9, 1.0, dm)
+            ref = oracle.evaluate(mode, c.x1, c.x2, c.rot_init, c.tran_init, 1.3, 0.9, 1.0, d12)
+            assert_normal_eq_close(got, ref, REL_TOL_F64, f"n={n} mode={mode} depth={dm}")
+            assert got.n_outlier == ref.n_outlier
+            assert abs(got.sum_w - ref.sum_w) <= REL_TOL_F64 * max(ref.sum_w, 1) or mode == api.MODE_ROT
+
+
+def test_reduction_golden_fixtures(problem):
+    z = np.load(GOLDEN / "reductions.npz", allow_pickle=False)
+    for n in (1, 63, 64, 65, 2048):
+        problem.upload(z[f"n{n}_x1"], z[f"n{n}_x2"], z[f"n{n}_d12"])
+        for mode in MODES:
+            for dm, key in ((api.DEPTH_UNIFORM, "u"), (api.DEPTH_PER_MATCH, "p")):
+                got = problem.eval(mode, z[f"n{n}_rot"], z[f"n{n}_tran"], 1.3, 0.9, 1.0, dm)
+                H, g, sc = z[f"n{n}_m{mode}_{key}_H"], z[f"n{n}_m{mode}_{key}_g"], z[f"n{n}_m{mode}_{key}_scalars"]
+                assert np.abs(got.H - H).max() <= REL_TOL_F64 * max(np.abs(H).max(), 1e-300)
+                assert np.abs(got.g - g).max() <= 10 * REL_TOL_F64 * max(np.abs(g).max(), 1e-300)
+                assert abs(got.cost - sc[0]) <= REL_TOL_F64 * sc[0] and got.n_outlier == sc[2]
+
+
+def test_pointwise_golden_fixtures(problem):
+    """n = 1 sweeps reproduce e and J of single residual blocks (incl. theta = 0, theta^2 < eps, theta ~ pi)."""
+    z = np.load(GOLDEN / "pointwise.npz", allow_pickle=False)
+    for i in range(len(z["mode"])):
+        mode = int(z["mode"][i])
+        problem.upload(z["x1"][i][None], z["x2"][i][None])
+        got = problem.eval(mode, z["rot"][i], z["tran"][i], float(z["d1"][i]), float(z["d2"][i]), 0.0)   # no loss
+        e, J = z["e"][i], z["J"][i]
+        scale = max(np.abs(J.T @ J).max(), 1e-300)
+        assert np.abs(got.H - J.T @ J).max() <= 1e-13 * scale, (z["case"][i], mode)
+        assert np.abs(got.g - J.T @ e).max() <= 1e-13 * max(np.abs(J.T @ e).max(), scale), (z["case"][i], mode)
+        assert abs(got.cost - 0.5 * e @ e) <= 1e-14 * max(e @ e, 1e-300)
+        # with Huber(1): cost = rho/2, weight = rho'
+        goth = problem.eval(mode, z["rot"][i], z["tran"][i], float(z["d1"][i]), float(z["d2"][i]), 1.0)
+        rho = z["rho"][i]
+        assert abs(goth.cost - 0.5 * rho[0]) <= 4e-16 * max(rho[0], 1e-300) * 8
+        assert np.abs(goth.H - rho[1] * (J.T @ J)).max() <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("delta", [0.0, 0.05, 1.0, 100.0])
+def test_huber_regions(problem, oracle, delta):
+    """delta = 0: no loss; 0.05: nearly everything is an outlier; 100: nothing is."""
+    c = synthetic.rotation_only(5000, seed=91, outlier_fraction=0.2)
+    problem.upload(c.x1, c.x2)
+    for mode in MODES:
+        got = problem.eval(mode, c.rot_init, [0.01, -0.02, 0.03], 1.0, 1.0, delta)
+        ref = oracle.evaluate(mode, c.x1, c.x2, c.rot_init, [0.01, -0.02, 0.03], 1.0, 1.0, delta)
+        assert_normal_eq_close(got, ref, REL_TOL_F64, f"delta={delta} mode={mode}")
+        assert got.n_outlier == ref.n_outlier
+    if delta == 100.0:
+        assert got.n_outlier == 0
+    if delta == 0.05:
+        assert got.n_outlier > 4000
+
+
+def test_empty_and_reupload(problem, oracle):
+    problem.upload(np.zeros((0, 3)), np.zeros((0, 3)))
+    got = problem.eval(api.MODE_RT, [0.1, 0.2, 0.3], [0, 0, 1.0])
+    assert not got.H.any() and not got.g.any() and got.cost == 0 and problem.size == 0
+    r, t, s = problem.solve(api.MODE_RT, [0.1, 0.2, 0.3], [0, 0, 1.0])
+    assert s.termination == "CONVERGENCE_GRADIENT" and s.num_evaluations == 1
+    # a smaller upload after a larger one must not see stale data
+    c = synthetic.rotation_only(777, seed=5)
+    problem.upload(c.x1, c.x2)
+    c2 = synthetic.rotation_only(33, seed=6)
+    problem.upload(c2.x1, c2.x2)
+    got = problem.eval(api.MODE_ROT, c2.rot_init, c2.tran_init)
+    assert_normal_eq_close(got, oracle.evaluate(0, c2.x1, c2.x2, c2.rot_init, c2.tran_init), REL_TOL_F64)
+
+
+def test_error_behaviour(problem):
+    c = synthetic.rotation_only(10, seed=1)
+    problem.upload(c.x1, c.x2)                                    # no per-match depths uploaded
+    with pytest.raises(api.SbaError) as ei:
+        problem.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+    assert ei.value.code == -1
+    with pytest.raises(api.SbaError):
+        problem.eval(5, c.rot_init, c.tran_init)
+    with pytest.raises(api.SbaError):
+        problem.eval(api.MODE_ROT, [np.nan, 0, 0], c.tran_init)
+    with pytest.raises(api.SbaError):
+        api.Problem(99)
+    fresh = api.Problem(0)
+    with pytest.raises(api.SbaError) as ei:
+        fresh.eval(api.MODE_ROT, c.rot_init, c.tran_init)
+    assert ei.value.code == -4                                     # SBA_ERR_NOT_UPLOADED
+    fresh.close()
+
+
+def test_f32_planes(problem, oracle):
+    c = synthetic.full_rt(50001, seed=17)
+    problem.upload(c.x1, c.x2, c.d12, store=api.STORE_F32)
+    x1f, x2f = c.x1.astype(np.float32).astype(np.float64), c.x2.astype(np.float32).astype(np.float64)
+    for mode in MODES:
+        got = problem.eval(mode, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        # exact statement: f64 arithmetic on the f32-rounded inputs
+        assert_normal_eq_close(got, oracle.evaluate(mode, x1f, x2f, c.rot_init, c.tran_init, d12=c.d12), REL_TOL_F64,
+                               f"f32 planes mode={mode}")
+        # and close to the f64-input answer
+        assert_normal_eq_close(got, oracle.evaluate(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12), REL_TOL_F32)
+
+
+# ---- LM solves ---------------------------------------------------------------------------------------
+def test_solve_golden_and_oracle_lm(problem, oracle):
+    z = np.load(GOLDEN / "solves.npz", allow_pickle=False)
+    problem.upload(z["c1_x1"], z["c1_x2"])                        # config C1 twin: 2048 matches, rot-only
+    r, t, s = problem.solve(api.MODE_ROT, z["c1_rot0"], z["c1_tran0"])
+    assert np.abs(r - z["c1_rot"]).max() <= RT_TOL_F64 and np.array_equal(t, z["c1_tran0"])
+    assert [s.num_iterations, s.num_successful_steps] == list(z["c1_meta"][1:3])
+    problem.upload(z["rt_x1"], z["rt_x2"], z["rt_d12"])
+    for name, tp in (("rt6", api.TRAN_FREE), ("rt5", api.TRAN_SPHERE)):
+        r, t, s = problem.solve(api.MODE_RT, z["rt_rot0"], z["rt_tran0"], depth_mode=api.DEPTH_PER_MATCH,
+                                options=api.default_lm_options(tran_param=tp))
+        assert np.abs(r - z[f"{name}_rot"]).max() <= RT_TOL_F64 and np.abs(t - z[f"{name}_tran"]).max() <= RT_TOL_F64
+        assert [s.num_iterations, s.num_successful_steps] == list(z[f"{name}_meta"][1:3])
+        assert s.num_evaluations == s.num_iterations + 1          # one sweep per LM iteration
+
+
+def test_three_stage_order_like_solve_problem(problem, oracle):
+    """rot-only then tran-only with the uniform init_d quirk (.cpp:202-209, :941-942, :998-999)."""
+    c = synthetic.full_rt(4000, seed=23, outlier_fraction=0.02)
+    problem.upload(c.x1, c.x2, c.d12)
+    d1, d2 = float(c.d12[0, 0]), float(c.d12[1, 0])               # init_d[0][0], init_d[1][0]
+    r, t, _ = problem.solve(api.MODE_ROT, c.rot_init, c.tran_init, d1, d2)
+    r2, t2, _ = problem.solve(api.MODE_TRAN, r, t, d1, d2)
+    ro, to, _, _ = oracle.lm_solve(0, c.x1, c.x2, c.rot_init, c.tran_init, d1, d2)
+    ro2, to2, _, _ = oracle.lm_solve(1, c.x1, c.x2, ro, to, d1, d2)
+    assert np.abs(r - ro).max() <= RT_TOL_F64 and np.array_equal(r2, r)
+    assert np.abs(t2 - to2).max() <= RT_TOL_F64 and np.array_equal(t, c.tran_init)
+
+
+def test_known_answer_noise_free(problem):
+    tight = dict(function_tolerance=1e-30, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    c = synthetic.rotation_only(20000, seed=61, sigma=0.0, outlier_fraction=0.0)
+    problem.upload(c.x1, c.x2)
+    r, _, s = problem.solve(api.MODE_ROT, c.rot_init, c.tran_init, options=api.default_lm_options(**tight))
+    assert np.abs(r - c.rot_true).max() <= RT_TOL_F64
+    c = synthetic.full_rt(20000, seed=62, sigma=0.0, outlier_fraction=0.0)
+    problem.upload(c.x1, c.x2, c.d12)
+    for tp in (api.TRAN_FREE, api.TRAN_SPHERE):
+        r, t, s = problem.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH,
+                                options=api.default_lm_options(tran_param=tp, **tight))
+        assert np.abs(r - c.rot_true).max() <= RT_TOL_F64 and np.abs(t - c.tran_true).max() <= RT_TOL_F64
+    problem.upload(c.x1, c.x2, c.d12, store=api.STORE_F32)
+    r, t, s = problem.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH,
+                            options=api.default_lm_options(**tight))
+    assert np.abs(r - c.rot_true).max() <= RT_TOL_F32 and np.abs(t - c.tran_true).max() <= RT_TOL_F32
+
+
+# ---- size-independent properties at BASELINE.json's full single-GPU sizes ------------------------------
+@pytest.mark.parametrize("n,gen,mode,dm", [(1_000_000, "rot", api.MODE_ROT, api.DEPTH_UNIFORM),
+                                           (10_000_000, "rt", api.MODE_RT, api.DEPTH_PER_MATCH)])
+def test_full_size_properties(oracle, n, gen, mode, dm):
+    c = synthetic.rotation_only(n, seed=synthetic.BASE_SEED + 1) if gen == "rot" else synthetic.full_rt(n)
+    d12 = c.d12 if dm == api.DEPTH_PER_MATCH else None
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, d12)
+        full = p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm)
+        # determinism: the fixed-order reduction makes repeated sweeps bit-identical
+        assert np.array_equal(full, p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm))
+        # oracle on a bounded prefix + additivity over shards (the multi-GPU sharding identity)
+        k = 200_000
+        p.upload(c.x1[:k], c.x2[:k], None if d12 is None else d12[:k])
+        head = p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm)
+        ref = pack_from_eval(mode, oracle.evaluate(mode, c.x1[:k], c.x2[:k], c.rot_init, c.tran_init,
+                                                   d12=None if d12 is None else d12[:k]))
+        assert np.abs(head - ref).max() <= REL_TOL_F64 * np.abs(ref).max()
+        p.upload(c.x1[k:], c.x2[k:], None if d12 is None else d12[k:])
+        tail = p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm)
+        assert np.abs(head + tail - full).max() <= REL_TOL_F64 * np.abs(full).max()
+        assert head[23] + tail[23] == full[23]                      # outlier counts are exact integers
+        # the generating R|t is (nearly) stationary: gradient tiny relative to the start point's
+        p.upload(c.x1, c.x2, d12)
+        at_truth = p.eval_pack(mode, c.rot_true, c.tran_true, depth_mode=dm)
+        assert at_truth[22] < full[22]
+        # and the solve stage converges to it within the noise level
+        r, t, s = p.solve(mode, c.rot_init, c.tran_init, depth_mode=dm)
+        assert s.termination.startswith("CONVERGENCE") and np.abs(r - c.rot_true).max() < 5e-3

@@ -1,0 +1,61 @@
+"""GPU (-m gpu): callers / data formats either side of the path -- pixel->sphere, equi2cube, RCCL hook."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from spherical_bundle_adjuster_amd import api, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_keypoints_to_sphere(oracle):
+    rng = np.random.default_rng(3)
+    n, W, H = 20001, 3840, 1920
+    kp = np.zeros((n, 7), dtype=np.float32)            # cv::KeyPoint: 28-byte records, pt.x pt.y first
+    kp[:, 0] = rng.uniform(0, W, n)
+    kp[:, 1] = rng.uniform(0, H, n)
+    kp[:4, :2] = [[0, 0], [W, H], [W / 2, H / 2], [0, H]]
+    got = api.keypoints_to_sphere(kp, W, H)
+    ref = oracle.keypoints_to_sphere(kp, W, H)
+    # device sin/cos vs glibc: a few ulp
+    assert np.abs(got - ref).max() <= 4e-16
+    assert np.abs(np.linalg.norm(got, axis=1) - 1).max() <= 4e-16
+    assert api.keypoints_to_sphere(kp[:0], W, H).shape == (0, 3)
+
+
+@pytest.mark.parametrize("H,W,S", [(64, 128, 16), (480, 960, 150), (1920, 3840, 600), (100, 200, 33)])
+def test_equi2cube_bit_exact(oracle, H, W, S):
+    """Byte-exact against the oracle (integer index work): every output pixel identical."""
+    rng = np.random.default_rng(H + S)
+    im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    got = api.equi2cube(im, S)
+    ref, clamped = oracle.equi2cube(im, S, clamp=True)
+    assert clamped == (1 if S % 2 == 0 else 0)         # the reference's south-pole overrun (equi2cube.cpp:47-50)
+    mism = int((got != ref).any(axis=2).sum())
+    assert mism == 0, f"{mism} of {S * 6 * S} pixels differ"
+
+
+def test_rccl_single_rank_and_hook():
+    """nranks = 1 native RCCL all-reduce and the user hook both leave the pack unchanged / scaled."""
+    c = synthetic.rotation_only(10000, seed=4)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2)
+        base = p.eval_pack(api.MODE_ROT, c.rot_init, c.tran_init)
+        calls = []
+
+        def hook(ptr, count, stream):
+            calls.append((ptr, count))
+            return 0
+        p.set_allreduce(hook)
+        assert np.array_equal(p.eval_pack(api.MODE_ROT, c.rot_init, c.tran_init), base)
+        assert calls and calls[0] == (p.pack_device_ptr, 24)
+        p.set_allreduce(lambda *a: 3)
+        with pytest.raises(api.SbaError) as ei:
+            p.eval_pack(api.MODE_ROT, c.rot_init, c.tran_init)
+        assert ei.value.code == -5
+        p.set_allreduce(None)
+        p.comm_init_rank(1, 0, api.comm_unique_id())
+        assert np.array_equal(p.eval_pack(api.MODE_ROT, c.rot_init, c.tran_init), base)
+        r, t, s = p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
+        assert s.termination.startswith("CONVERGENCE")

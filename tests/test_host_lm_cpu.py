@@ -1,0 +1,136 @@
+"""CPU: the product's host LM (csrc/sba_lm.hpp) driven by the oracle sweep through the test harness
+must reproduce the oracle's own LM restatement iterate-for-iterate, and the sharded (world_size 2,
+gloo) path must agree with the single-process one."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, harness_solve, pack_from_eval
+from spherical_bundle_adjuster_amd import synthetic
+
+
+def _oracle_evaluator(oracle, mode, c, per_match, delta=1.0):
+    d12 = c.d12 if per_match else None
+    return lambda r, t: pack_from_eval(mode, oracle.evaluate(mode, c.x1, c.x2, r, t, 1.0, 1.0, delta, d12, threads=1))
+
+
+@pytest.mark.parametrize("mode,per_match,tp", [(0, False, 0), (1, True, 0), (2, True, 0), (2, True, 1), (1, True, 1)])
+def test_host_lm_matches_oracle_lm(oracle, mode, per_match, tp):
+    c = synthetic.full_rt(1500, seed=31) if per_match else synthetic.rotation_only(1500, seed=32)
+    r, t, s, rc = harness_solve(mode, c.rot_init, c.tran_init, _oracle_evaluator(oracle, mode, c, per_match),
+                                tran_param=tp)
+    ro, to, so, rco = oracle.lm_solve(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12 if per_match else None,
+                                      options=oracle.default_options(tran_param=tp), threads=1)
+    assert rc == 0 and rco == 0
+    assert (s.termination, s.num_iterations, s.num_successful_steps, s.num_evaluations) == \
+           (so.termination, so.num_iterations, so.num_successful_steps, so.num_evaluations)
+    assert np.abs(r - ro).max() < 1e-13 and np.abs(t - to).max() < 1e-13
+    assert abs(s.final_cost - so.final_cost) <= 1e-13 * so.final_cost
+
+
+def test_host_lm_golden_solves(oracle):
+    z = np.load(GOLDEN / "solves.npz", allow_pickle=False)
+
+    class C1:
+        x1, x2, d12 = z["c1_x1"], z["c1_x2"], None
+    r, t, s, rc = harness_solve(0, z["c1_rot0"], z["c1_tran0"], _oracle_evaluator(oracle, 0, C1, False))
+    assert rc == 0 and np.abs(r - z["c1_rot"]).max() < 1e-13
+    assert [s.termination, s.num_iterations, s.num_successful_steps] == list(z["c1_meta"][:3])
+
+    class RT:
+        x1, x2, d12 = z["rt_x1"], z["rt_x2"], z["rt_d12"]
+    for name, tp in (("rt6", 0), ("rt5", 1)):
+        r, t, s, rc = harness_solve(2, z["rt_rot0"], z["rt_tran0"], _oracle_evaluator(oracle, 2, RT, True), tran_param=tp)
+        assert rc == 0 and np.abs(r - z[f"{name}_rot"]).max() < 1e-12 and np.abs(t - z[f"{name}_tran"]).max() < 1e-12
+        assert [s.termination, s.num_iterations, s.num_successful_steps] == list(z[f"{name}_meta"][:3])
+
+
+def test_host_lm_known_answer_and_limits(oracle):
+    c = synthetic.full_rt(400, seed=41, sigma=0.0, outlier_fraction=0.0)
+    ev = _oracle_evaluator(oracle, 2, c, True)
+    r, t, s, rc = harness_solve(2, c.rot_init, c.tran_init, ev, function_tolerance=1e-30, parameter_tolerance=1e-14,
+                                gradient_tolerance=1e-16)
+    assert rc == 0 and np.abs(r - c.rot_true).max() < 1e-10 and np.abs(t - c.tran_true).max() < 1e-10
+    # iteration cap is honoured and reported
+    r, t, s, rc = harness_solve(2, c.rot_init, c.tran_init, ev, max_num_iterations=2, function_tolerance=0.0,
+                                parameter_tolerance=0.0, gradient_tolerance=0.0)
+    assert rc == 0 and s.termination == 4 and s.num_iterations == 2 and s.num_evaluations == 3
+    # already at the optimum: gradient convergence at iteration 0 with a single sweep
+    r, t, s, rc = harness_solve(2, c.rot_true, c.tran_true, ev, gradient_tolerance=1e-9)
+    assert rc == 0 and s.termination == 2 and s.num_iterations == 0 and s.num_evaluations == 1
+    # an evaluator failure surfaces as an error, not as a result
+    def bad(r_, t_):
+        raise RuntimeError("boom")
+    _, _, s, rc = harness_solve(2, c.rot_init, c.tran_init, bad)
+    assert rc != 0 and s.termination == 6
+    # non-finite cost is rejected
+    _, _, s, rc = harness_solve(2, c.rot_init, c.tran_init, lambda r_, t_: np.full(24, np.nan))
+    assert rc != 0
+
+
+def test_empty_problem_converges_immediately():
+    r, t, s, rc = harness_solve(2, [0.1, 0.2, 0.3], [0, 0, 1.0], lambda r_, t_: np.zeros(24))
+    assert rc == 0 and s.termination == 2 and s.num_evaluations == 1 and np.array_equal(r, [0.1, 0.2, 0.3])
+
+
+# ---- world_size 2, gloo -------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from helpers import harness_solve as hs, pack_from_eval as pfe
+    from oracle import oracle_py as orc
+    from spherical_bundle_adjuster_amd import synthetic as syn
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = syn.full_rt(3001, seed=51)           # odd size: ragged shards
+    lo, hi = syn.shard_range(3001, rank, world)
+    calls = [0]
+
+    def evaluator(r, t):
+        p = pfe(2, orc.evaluate(2, c.x1[lo:hi], c.x2[lo:hi], r, t, 1.0, 1.0, 1.0, c.d12[lo:hi], threads=1))
+        tp = torch.from_numpy(p)
+        dist.all_reduce(tp)                   # ONE all-reduce of the 24-double pack per LM iteration
+        calls[0] += 1
+        return tp.numpy()
+    r, t, s, rc = hs(2, c.rot_init, c.tran_init, evaluator)
+    q.put((rank, r, t, s.num_iterations, s.num_evaluations, calls[0], rc, (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_sharded_gloo_world2_matches_single(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=180) for _ in procs])
+    [p.join(60) for p in procs]
+    c = synthetic.full_rt(3001, seed=51)
+    r1, t1, s1, rc1 = harness_solve(2, c.rot_init, c.tran_init, _oracle_evaluator(oracle, 2, c, True))
+    assert rc1 == 0
+    assert res[0][7] == (0, 1501) and res[1][7] == (1501, 3001)
+    for rank, r, t, iters, evals, calls, rc, _ in res:
+        assert rc == 0 and iters == s1.num_iterations and evals == s1.num_evaluations
+        assert calls == evals                       # exactly one collective per sweep
+        assert np.abs(r - r1).max() < 1e-12 and np.abs(t - t1).max() < 1e-12
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])   # ranks stay in lock-step
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 9, 100000007):
+        for world in (1, 2, 3, 8):
+            spans = [synthetic.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(lo <= hi for lo, hi in spans)
