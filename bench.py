@@ -45,7 +45,20 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--transport", choices=["auto", "native", "hook"], default="auto")
+    ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(c, mode, per_match, sample, seconds):
@@ -55,18 +68,18 @@ def cpu_baseline(c, mode, per_match, sample, seconds):
     n = min(sample, c.x1.shape[0])
     x1, x2 = c.x1[:n], c.x2[:n]
     d12 = c.d12[:n] if per_match else None
-    cores = orc.num_procs()
-    orc.evaluate(mode, x1[:10000], x2[:10000], c.rot_init, c.tran_init, d12=None if d12 is None else d12[:10000])
+    cores = min(orc.num_procs(), usable_cores())
+    orc.evaluate(mode, x1[:10000], x2[:10000], c.rot_init, c.tran_init, d12=None if d12 is None else d12[:10000], threads=cores)
     passes, t0 = 0, time.perf_counter()
     while True:
-        orc.evaluate(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12)
+        orc.evaluate(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12, threads=cores)
         passes += 1
         el = time.perf_counter() - t0
         if el >= seconds or passes >= 50:
             break
     faithful = n * passes / el
     t0 = time.perf_counter()
-    orc.evaluate_hoisted(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12)
+    orc.evaluate_hoisted(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12, threads=cores)
     hoisted = n / (time.perf_counter() - t0)
     return {"value": faithful, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{passes} passes over the first {n} correspondences of the workload, faithful "
@@ -110,6 +123,7 @@ def main():
     use_hook = world > 1 and a.transport == "hook"
     stream = torch.cuda.current_stream().cuda_stream if use_hook else None
     p = api.Problem(local_rank, stream=stream)
+    p.set_kernel(api.KERNEL_EXPLICIT if a.kernel == "explicit" else api.KERNEL_FACTORED)
     p.upload(c.x1, c.x2, c.d12 if rt else None, store=store)
     transport = "none"
     if world > 1:
@@ -155,7 +169,7 @@ def main():
                                     "depths (BASELINE config C3)" if rt and a.n == 10_000_000 else
                                     f"{a.n} synthetic correspondences per GPU, {a.workload} sweep"),
                        "correspondences_per_gpu": a.n, "mode": a.workload, "storage": a.store,
-                       "bytes_per_eval": bytes_per_eval, "allreduce": transport,
+                       "bytes_per_eval": bytes_per_eval, "allreduce": transport, "kernel": a.kernel,
                        "step": "sweep + finalize + all-reduce(24 f64) + D2H(192 B) + host sync"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

@@ -78,6 +78,13 @@ enum {
   SBA_STORE_F32 = 1  /* 24 B / correspondence (32 B): arithmetic stays f64                    */
 };
 
+/* ---- which sweep kernel evaluates the Jacobian terms (results agree to rounding) ---------------- */
+enum {
+  SBA_KERNEL_FACTORED = 0, /* default: d e/d rot = -[v]x J_l(rot), v = -d1 R x1; the device accumulates the
+                              moments sum w v v^T, sum w v e^T, sum w v and the host applies J_l          */
+  SBA_KERNEL_EXPLICIT = 1  /* the 3x3 Jacobian block d e/d rot is formed per match on the device          */
+};
+
 /* ---- translation parameterisation in SBA_MODE_RT / SBA_MODE_TRAN ---------------------- */
 enum {
   SBA_TRAN_FREE = 0,   /* 3 free components, additive update (reference behaviour)            */
@@ -180,6 +187,9 @@ int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const vo
                               const void* d12_dev, size_t n, int store);
 
 int sba_problem_size(const sba_problem* p, size_t* n);
+/* Select the sweep kernel (SBA_KERNEL_*); also settable with the environment variable
+ * SBA_KERNEL=explicit at sba_problem_create time.                                                 */
+int sba_problem_set_kernel(sba_problem* p, int kind);
 
 /* ---- one residual + Jacobian sweep ------------------------------------------------------ */
 /* Evaluates all local correspondences at (rot, tran), reduces on the device, all-reduces if a
@@ -230,7 +240,8 @@ int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]);
 int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]);
 /* Option B: user hook (e.g. torch.distributed.all_reduce on a tensor aliasing device_buf).  */
 int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
-/* Device address of the 24-double result pack the hook / RCCL operates on.                  */
+/* Device address of the 24-double result pack the hook / RCCL operates on (a sum over
+ * correspondences in either kernel's layout, so summing it across shards is exact).            */
 int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);
 
 /* ---- callers / data formats either side of the path ------------------------------------- */

@@ -21,6 +21,7 @@ MODE_ROT, MODE_TRAN, MODE_RT = 0, 1, 2
 DEPTH_UNIFORM, DEPTH_PER_MATCH = 0, 1
 STORE_F64, STORE_F32 = 0, 1
 TRAN_FREE, TRAN_SPHERE = 0, 1
+KERNEL_FACTORED, KERNEL_EXPLICIT = 0, 1
 PACK_SIZE = 24
 COMM_ID_BYTES = 128
 TERMINATION = {1: "CONVERGENCE_FUNCTION", 2: "CONVERGENCE_GRADIENT", 3: "CONVERGENCE_PARAMETER",
@@ -84,6 +85,7 @@ SIGNATURES = {
     "sba_problem_upload": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
     "sba_problem_upload_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
     "sba_problem_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "sba_problem_set_kernel": (C.c_int, [_vp, C.c_int]),
     "sba_problem_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                    C.c_double, C.POINTER(NormalEq)]),
     "sba_problem_eval_pack": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,

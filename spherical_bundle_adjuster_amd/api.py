@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _cabi as cabi
-from ._cabi import (DEPTH_PER_MATCH, DEPTH_UNIFORM, MODE_ROT, MODE_RT, MODE_TRAN, STORE_F32,  # noqa: F401
+from ._cabi import (DEPTH_PER_MATCH, DEPTH_UNIFORM, KERNEL_EXPLICIT, KERNEL_FACTORED, MODE_ROT, MODE_RT, MODE_TRAN, STORE_F32,  # noqa: F401
                     STORE_F64, TRAN_FREE, TRAN_SPHERE, SbaError)
 
 
@@ -129,6 +129,10 @@ class Problem:
                       store: int = STORE_F64) -> None:
         cabi.check(self._lib, self._lib.sba_problem_upload_device(
             self._h, C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_void_p(d12_ptr or 0), n, store))
+
+    def set_kernel(self, kind: int) -> None:
+        """KERNEL_FACTORED (default) or KERNEL_EXPLICIT."""
+        cabi.check(self._lib, self._lib.sba_problem_set_kernel(self._h, kind))
 
     @property
     def size(self) -> int:

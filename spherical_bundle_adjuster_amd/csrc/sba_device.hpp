@@ -37,8 +37,10 @@ constexpr int kBlock = 256;
 
 // Sweep: residual + Jacobian + Huber + reduction of every block's partial pack into
 // partials[grid][24]; then finalize() folds the partials in a fixed order into pack_out[24].
-hipError_t launch_sweep(int mode, int depth, int store, const Planes& pl, const SweepParams& prm,
+// kind: 0 = factored (moment pack, host applies J_l), 1 = explicit per-match Jacobian (SBA_PACK layout).
+hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& pl, const SweepParams& prm,
                         double* partials, int grid, hipStream_t stream);
+hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream);
 
 // AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.

@@ -1,23 +1,29 @@
 // HIP kernels (gfx950 / CDNA4, wave64) of the spherical bundle-adjustment hot path.
 //
-// sweep_kernel<MODE, DEPTH, ST> is the fused replacement of one Ceres residual+Jacobian
-// evaluation over all residual blocks (reference spherical_bundle_adjuster.cpp:843-868,
-// :891-919, :947-976 evaluated through AutoDiffCostFunction + HuberLoss(1.0), :887/:943/:1000):
+// sweep kernels = the fused replacement of one Ceres residual+Jacobian evaluation over all residual
+// blocks (reference spherical_bundle_adjuster.cpp:843-868, :891-919, :947-976 evaluated through
+// AutoDiffCostFunction + HuberLoss(1.0), :887/:943/:1000).  Per correspondence i ("one evaluation"):
 //
-//   per correspondence i (one "evaluation"):
-//       e  = t + d2 x2_i + d1 Rn x1_i                        residual            (.cpp:897-916)
-//       A  = d1 [Gn_0 x1_i | Gn_1 x1_i | Gn_2 x1_i]          d e / d rot  (what Jet<double,3> carries)
-//       s  = e.e ;  w = rho'(s) ;  rho(s)                    block-wise Huber (Ceres corrector with
-//                                                            rho'' <= 0: scale e and J by sqrt(w))
-//       acc += w A^T A, w A^T, w, w A^T e, w e, rho/2        23 running sums (+ outlier count)
+//       v  = d1 Rn x1_i            (Rn = -R, or -d1 R with uniform depths)
+//       e  = t + d2 x2_i + v                                   residual            (.cpp:897-916)
+//       s  = e.e ;  w = rho'(s) ;  rho(s)                      block-wise Huber (Ceres corrector with
+//                                                              rho'' <= 0: scale e and J by sqrt(w))
+//   KIND_FACTORED (default):  d e/d rot = A = -[v]x J_l(rot) with J_l constant per sweep, so the
+//       normal equations factor through moments of v and e; the kernel accumulates
+//           M = sum w v v^T (6), C = sum w v e^T (9), m = sum w v (3), sum w e (3), sum w, cost
+//       and the host applies J_l (sba_rotation.hpp: moments_to_normal_pack).
+//   KIND_EXPLICIT:  A = d1 [Gn_0 x1 | Gn_1 x1 | Gn_2 x1] formed per match (what Jet<double,3> carries),
+//           acc += w A^T A, w A^T, w, w A^T e, w e, rho/2
+//       kept as the independent cross-check of the factored form.
 //   wave:   DPP butterfly over the 64 lanes
 //   block:  4 waves through LDS -> partials[block][24]
 //   grid:   finalize_kernel folds partials in a fixed order -> pack[24]  (deterministic)
 //
-// Memory: the six coordinate planes are read exactly once, 16 B per lane per load instruction
-// (1 KiB contiguous per wave instruction).  No reuse, no MFMA: the kernel is HBM-bound
-// (48 B per evaluation with f64 planes and uniform depths).  The wave-uniform R|t state
-// (SweepParams) arrives as a by-value kernel argument and is staged once per block in LDS.
+// Memory: the coordinate planes are read exactly once, 16 B per lane per load instruction (1 KiB
+// contiguous per wave instruction), next vector prefetched into registers while the current one is
+// consumed.  No reuse, no MFMA: HBM-bound (48 B per evaluation with f64 planes and uniform depths,
+// 64 B with per-match depths).  The wave-uniform R|t state (SweepParams) is a by-value kernel argument:
+// scalar loads, operands stay in SGPRs (SBA_PARAMS_IN_LDS=1 stages it in LDS instead).
 #include "sba_device.hpp"
 
 #ifndef SBA_PARAMS_IN_LDS
@@ -29,22 +35,29 @@ namespace {
 
 constexpr int MODE_ROT = 0, MODE_TRAN = 1, MODE_RT = 2;
 constexpr int DEPTH_UNIFORM = 0, DEPTH_PER_MATCH = 1;
+constexpr int KIND_FACTORED = 0, KIND_EXPLICIT = 1;
 
 // ---- accumulator <-> pack slot maps -------------------------------------------------------
-template <int MODE> struct AccMap;
-template <> struct AccMap<MODE_ROT> {   // haa[6] ga[3] cost nout
+// explicit pack = SBA_PACK_* of sba_hip.h; moment pack: [0..5] M, [6..14] C, [15] sw, [16..18] m,
+// [19..21] sum w e, [22] cost, [23] n_outlier.  Slots 15 and 19..23 mean the same in both.
+template <int MODE, int KIND> struct AccMap;
+template <> struct AccMap<MODE_ROT, KIND_EXPLICIT> {   // haa[6] ga[3] cost nout
   static constexpr int N = 11;
   __host__ __device__ static constexpr int slot(int k) {
     return k < 6 ? k : (k < 9 ? 16 + (k - 6) : (k == 9 ? 22 : 23));
   }
 };
-template <> struct AccMap<MODE_TRAN> {  // sw gt[3] cost nout
+template <> struct AccMap<MODE_ROT, KIND_FACTORED> {   // M[6] C[9] cost nout
+  static constexpr int N = 17;
+  __host__ __device__ static constexpr int slot(int k) { return k < 15 ? k : (k == 15 ? 22 : 23); }
+};
+template <int KIND> struct AccMap<MODE_TRAN, KIND> {   // sw gt[3] cost nout
   static constexpr int N = 6;
   __host__ __device__ static constexpr int slot(int k) {
     return k == 0 ? 15 : (k < 4 ? 19 + (k - 1) : (k == 4 ? 22 : 23));
   }
 };
-template <> struct AccMap<MODE_RT> {    // the full pack
+template <int KIND> struct AccMap<MODE_RT, KIND> {     // the full pack, either layout
   static constexpr int N = 24;
   __host__ __device__ static constexpr int slot(int k) { return k; }
 };
@@ -67,28 +80,42 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   return v;
 }
 
-// ---- vector loads: 16 bytes per lane ---------------------------------------------------------
-template <typename ST> struct Vec;
-template <> struct Vec<double> {
-  static constexpr int PPT = 2;
-  double v[2];
-  __device__ __forceinline__ void load(const void* plane, size_t vec_index) {
-    const double2 q = reinterpret_cast<const double2*>(plane)[vec_index];
-    v[0] = q.x; v[1] = q.y;
+// ---- one 16-byte vector of correspondences per lane: 2 points (f64 planes) or 4 (f32 planes) ---
+template <typename ST> struct Lanes;
+template <> struct Lanes<double> { static constexpr int PPT = 2; typedef double2 vec; };
+template <> struct Lanes<float> { static constexpr int PPT = 4; typedef float4 vec; };
+
+template <typename ST, int DEPTH>
+struct VecRegs {
+  static constexpr int PPT = Lanes<ST>::PPT;
+  typename Lanes<ST>::vec c[6];        // x1.x x1.y x1.z x2.x x2.y x2.z
+  double2 d1[PPT / 2], d2[PPT / 2];    // per-match depths (always f64)
+  __device__ __forceinline__ void load(const Planes& pl, size_t p) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      c[k] = reinterpret_cast<const typename Lanes<ST>::vec*>(pl.x1[k])[p];
+      c[3 + k] = reinterpret_cast<const typename Lanes<ST>::vec*>(pl.x2[k])[p];
+    }
+    if (DEPTH == DEPTH_PER_MATCH) {
+#pragma unroll
+      for (int h = 0; h < PPT / 2; ++h) {
+        d1[h] = reinterpret_cast<const double2*>(pl.d1)[p * (PPT / 2) + h];
+        d2[h] = reinterpret_cast<const double2*>(pl.d2)[p * (PPT / 2) + h];
+      }
+    }
   }
-};
-template <> struct Vec<float> {
-  static constexpr int PPT = 4;
-  double v[4];
-  __device__ __forceinline__ void load(const void* plane, size_t vec_index) {
-    const float4 q = reinterpret_cast<const float4*>(plane)[vec_index];
-    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  __device__ __forceinline__ double coord(int k, int h) const {
+    if (PPT == 2) return h == 0 ? static_cast<double>(c[k].x) : static_cast<double>(c[k].y);
+    const float4& q = reinterpret_cast<const float4&>(c[k]);
+    return h == 0 ? q.x : (h == 1 ? q.y : (h == 2 ? q.z : q.w));
   }
+  __device__ __forceinline__ double depth1(int h) const { return (h & 1) ? d1[h >> 1].y : d1[h >> 1].x; }
+  __device__ __forceinline__ double depth2(int h) const { return (h & 1) ? d2[h >> 1].y : d2[h >> 1].x; }
 };
 
-// ---- Huber: w = rho'(s), r = rho(s) ---------------------------------------------------------
-// Outlier region needs 1/sqrt(s): v_rsq_f64 seed + two Newton steps (full f64 accuracy to a
-// couple of ulp) instead of the library sqrt + divide (~40 instructions).
+// ---- Huber: w = rho'(s), rho(s) ---------------------------------------------------------------
+// Outlier region needs 1/sqrt(s): v_rsq_f64 seed + two Newton steps (f64 accuracy to ~2 ulp) instead of
+// the library sqrt + divide (~40 instructions).  Inlier lanes discard the (possibly inf/nan) seed.
 __device__ __forceinline__ void huber(double s, double delta, double delta2, double& w, double& rho,
                                       double& is_out) {
   double y = __builtin_amdgcn_rsq(s);
@@ -96,28 +123,25 @@ __device__ __forceinline__ void huber(double s, double delta, double delta2, dou
   y = y * __builtin_fma(-hs * y, y, 1.5);
   y = y * __builtin_fma(-hs * y, y, 1.5);
   const bool out = s > delta2;
-  const double sq = s * y;                                     // sqrt(s)
   w = out ? delta * y : 1.0;
-  rho = out ? __builtin_fma(2.0 * delta, sq, -delta2) : s;
+  rho = out ? __builtin_fma(2.0 * delta, s * y, -delta2) : s;
   is_out = out ? 1.0 : 0.0;
 }
 
 // ---- one correspondence ------------------------------------------------------------------------
-// P points at the LDS copy of SweepParams (wave-uniform address -> broadcast reads).
-template <int MODE, int DEPTH>
-__device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, bool use_loss,
-                                           double x, double y, double z, double u, double v,
-                                           double q, double d1, double d2, bool valid,
-                                           double* __restrict__ acc) {
-  // r = Rn x1
+template <int MODE, int DEPTH, int KIND, bool LOSS>
+__device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, double x, double y,
+                                           double z, double u, double v, double q, double d1, double d2,
+                                           bool valid, double* __restrict__ acc) {
   double r0 = P->Rn[0] * x + P->Rn[1] * y + P->Rn[2] * z;
   double r1 = P->Rn[3] * x + P->Rn[4] * y + P->Rn[5] * z;
   double r2 = P->Rn[6] * x + P->Rn[7] * y + P->Rn[8] * z;
   double e0, e1, e2;
   if (DEPTH == DEPTH_PER_MATCH) {
-    e0 = __builtin_fma(d1, r0, __builtin_fma(d2, u, P->t[0]));
-    e1 = __builtin_fma(d1, r1, __builtin_fma(d2, v, P->t[1]));
-    e2 = __builtin_fma(d1, r2, __builtin_fma(d2, q, P->t[2]));
+    r0 *= d1; r1 *= d1; r2 *= d1;
+    e0 = r0 + __builtin_fma(d2, u, P->t[0]);
+    e1 = r1 + __builtin_fma(d2, v, P->t[1]);
+    e2 = r2 + __builtin_fma(d2, q, P->t[2]);
   } else {
     e0 = r0 + __builtin_fma(P->d2, u, P->t[0]);
     e1 = r1 + __builtin_fma(P->d2, v, P->t[1]);
@@ -125,7 +149,7 @@ __device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, bo
   }
   const double s = e0 * e0 + e1 * e1 + e2 * e2;
   double w = 1.0, rho = s, is_out = 0.0;
-  if (use_loss) huber(s, P->delta, P->delta2, w, rho, is_out);
+  if (LOSS) huber(s, P->delta, P->delta2, w, rho, is_out);
   if (!valid) { w = 0.0; rho = 0.0; is_out = 0.0; }
 
   if (MODE == MODE_TRAN) {
@@ -138,7 +162,41 @@ __device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, bo
     return;
   }
 
-  // A[r][j] = (Gn_j x1)[r]
+  if (KIND == KIND_FACTORED) {
+    const double wr0 = w * r0, wr1 = w * r1, wr2 = w * r2;
+    // M = sum w v v^T (upper)
+    acc[0] = __builtin_fma(wr0, r0, acc[0]);
+    acc[1] = __builtin_fma(wr0, r1, acc[1]);
+    acc[2] = __builtin_fma(wr0, r2, acc[2]);
+    acc[3] = __builtin_fma(wr1, r1, acc[3]);
+    acc[4] = __builtin_fma(wr1, r2, acc[4]);
+    acc[5] = __builtin_fma(wr2, r2, acc[5]);
+    // C = sum w v e^T
+    acc[6] = __builtin_fma(wr0, e0, acc[6]);
+    acc[7] = __builtin_fma(wr0, e1, acc[7]);
+    acc[8] = __builtin_fma(wr0, e2, acc[8]);
+    acc[9] = __builtin_fma(wr1, e0, acc[9]);
+    acc[10] = __builtin_fma(wr1, e1, acc[10]);
+    acc[11] = __builtin_fma(wr1, e2, acc[11]);
+    acc[12] = __builtin_fma(wr2, e0, acc[12]);
+    acc[13] = __builtin_fma(wr2, e1, acc[13]);
+    acc[14] = __builtin_fma(wr2, e2, acc[14]);
+    if (MODE == MODE_ROT) {
+      acc[15] = __builtin_fma(0.5, rho, acc[15]);
+      acc[16] += is_out;
+    } else {
+      acc[15] += w;
+      acc[16] += wr0; acc[17] += wr1; acc[18] += wr2;
+      acc[19] = __builtin_fma(w, e0, acc[19]);
+      acc[20] = __builtin_fma(w, e1, acc[20]);
+      acc[21] = __builtin_fma(w, e2, acc[21]);
+      acc[22] = __builtin_fma(0.5, rho, acc[22]);
+      acc[23] += is_out;
+    }
+    return;
+  }
+
+  // KIND_EXPLICIT: A[r][j] = (Gn_j x1)[r]
   double A[3][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -155,8 +213,6 @@ __device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, bo
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int j = 0; j < 3; ++j) wA[r][j] = w * A[r][j];
-
-  // sum w A^T A (upper), slots 0..5 : 00 01 02 11 12 22
   int k = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -173,7 +229,7 @@ __device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, bo
                    __builtin_fma(wA[1][a], e1, __builtin_fma(wA[2][a], e2, acc[6 + a])));
     acc[9] = __builtin_fma(0.5, rho, acc[9]);
     acc[10] += is_out;
-  } else {  // MODE_RT: full pack layout
+  } else {
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -191,40 +247,24 @@ __device__ __forceinline__ void accumulate(const SweepParams* __restrict__ P, bo
   }
 }
 
-// One 16-byte vector of correspondences per lane (2 with f64 planes, 4 with f32 planes).
-template <int MODE, int DEPTH, typename ST, bool CHECK>
-__device__ __forceinline__ void process_vec(const Planes& pl, const SweepParams* __restrict__ P,
-                                            bool use_loss, size_t p, size_t n,
-                                            double* __restrict__ acc) {
-  constexpr int PPT = Vec<ST>::PPT;
-  Vec<ST> ax, ay, az, bx, by, bz;
-  ax.load(pl.x1[0], p); ay.load(pl.x1[1], p); az.load(pl.x1[2], p);
-  bx.load(pl.x2[0], p); by.load(pl.x2[1], p); bz.load(pl.x2[2], p);
-  double d1v[PPT], d2v[PPT];
-  if (DEPTH == DEPTH_PER_MATCH) {
-#pragma unroll
-    for (int h = 0; h < PPT / 2; ++h) {
-      const double2 a = reinterpret_cast<const double2*>(pl.d1)[p * (PPT / 2) + h];
-      const double2 b = reinterpret_cast<const double2*>(pl.d2)[p * (PPT / 2) + h];
-      d1v[2 * h] = a.x; d1v[2 * h + 1] = a.y;
-      d2v[2 * h] = b.x; d2v[2 * h + 1] = b.y;
-    }
-  } else {
-#pragma unroll
-    for (int h = 0; h < PPT; ++h) { d1v[h] = 1.0; d2v[h] = 0.0; }
-  }
-  const size_t first = p * PPT;
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS, bool CHECK>
+__device__ __forceinline__ void consume(const VecRegs<ST, DEPTH>& r, const SweepParams* __restrict__ P,
+                                        size_t p, size_t n, double* __restrict__ acc) {
+  constexpr int PPT = Lanes<ST>::PPT;
 #pragma unroll
   for (int h = 0; h < PPT; ++h)
-    accumulate<MODE, DEPTH>(P, use_loss, ax.v[h], ay.v[h], az.v[h], bx.v[h], by.v[h], bz.v[h],
-                            d1v[h], d2v[h], CHECK ? (first + h < n) : true, acc);
+    accumulate<MODE, DEPTH, KIND, LOSS>(P, r.coord(0, h), r.coord(1, h), r.coord(2, h), r.coord(3, h),
+                                        r.coord(4, h), r.coord(5, h),
+                                        DEPTH == DEPTH_PER_MATCH ? r.depth1(h) : 1.0,
+                                        DEPTH == DEPTH_PER_MATCH ? r.depth2(h) : 0.0,
+                                        CHECK ? (p * PPT + h < n) : true, acc);
 }
 
-template <int MODE, int DEPTH, typename ST>
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams prm,
                                                       double* __restrict__ partials) {
-  constexpr int NACC = AccMap<MODE>::N;
-  constexpr int PPT = Vec<ST>::PPT;
+  constexpr int NACC = AccMap<MODE, KIND>::N;
+  constexpr int PPT = Lanes<ST>::PPT;
   // One LDS object: [0, 48) the staged R|t state (SBA_PARAMS_IN_LDS), then the cross-wave scratch.
   __shared__ double lds[48 + (kBlock / 64) * 24];
   double* wave_out = lds + 48;
@@ -236,8 +276,6 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams pr
 #else
   const SweepParams* P = &prm;   // kernarg segment: scalar loads, operands stay in SGPRs
 #endif
-
-  const bool use_loss = P->delta > 0.0;
   const size_t n = prm.n;
   const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
 
@@ -245,28 +283,38 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams pr
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-  // Full vectors: every lane valid, no masking in the hot loop.
+  // Full vectors: every lane valid, no masking in the hot loop.  The next vector's loads are issued
+  // before the current one is consumed (register double buffer), so each wave keeps 6-8 KiB in flight
+  // while its VALU works.
   const size_t nfull = n / PPT;
-#pragma unroll 2
-  for (size_t p = static_cast<size_t>(blockIdx.x) * kBlock + tid; p < nfull; p += stride)
-    process_vec<MODE, DEPTH, ST, false>(pl, P, use_loss, p, n, acc);
+  size_t p = static_cast<size_t>(blockIdx.x) * kBlock + tid;
+  VecRegs<ST, DEPTH> cur, nxt;
+  if (p < nfull) cur.load(pl, p);
+  while (p < nfull) {
+    const size_t pn = p + stride;
+    if (pn < nfull) nxt.load(pl, pn);
+    consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, P, p, n, acc);
+    cur = nxt;
+    p = pn;
+  }
   // Ragged tail (n % PPT != 0): one lane of the grid handles the last, partly valid vector
   // (the planes are zero-padded to a whole vector at upload).
-  if (nfull * PPT != n && blockIdx.x == gridDim.x - 1 && tid == kBlock - 1)
-    process_vec<MODE, DEPTH, ST, true>(pl, P, use_loss, nfull, n, acc);
+  if (nfull * PPT != n && blockIdx.x == gridDim.x - 1 && tid == kBlock - 1) {
+    cur.load(pl, nfull);
+    consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, P, nfull, n, acc);
+  }
 
   // wave -> lane 63 -> LDS -> block partial (pack layout, unused slots zero)
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int k = 0; k < NACC; ++k) {
     const double s = wave_sum_to_lane63(acc[k]);
-    if (lane == 63) wave_out[wave * 24 + AccMap<MODE>::slot(k)] = s;
+    if (lane == 63) wave_out[wave * 24 + AccMap<MODE, KIND>::slot(k)] = s;
   }
-  // slots this mode does not produce
-  if (NACC < 24 && tid < 24) {
+  if (NACC < 24 && tid < 24) {   // slots this mode does not produce
     bool used = false;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) used |= (AccMap<MODE>::slot(k) == tid);
+    for (int k = 0; k < NACC; ++k) used |= (AccMap<MODE, KIND>::slot(k) == tid);
     if (!used) {
 #pragma unroll
       for (int wv = 0; wv < kBlock / 64; ++wv) wave_out[wv * 24 + tid] = 0.0;
@@ -281,21 +329,30 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams pr
   }
 }
 
-// Fold partials[nblocks][24] in a fixed order: 8 strided serial chains per slot, then a serial
-// sum of the 8 chains.  One block; independent of timing, so results are run-to-run identical.
-__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ partials,
-                                                       int nblocks, double* __restrict__ pack_out) {
-  __shared__ double part[8][32];
+// Fold partials[nblocks][24] in a fixed order.  1024 threads = 32 slots x 32 groups: group g sums
+// blocks g, g+32, ... for its slot (4 independent chains so the loads pipeline), then the 32 groups are
+// summed serially per slot.  Independent of timing, so results are run-to-run identical.
+__global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict__ partials,
+                                                        int nblocks, double* __restrict__ pack_out) {
+  __shared__ double part[32][33];
   const int slot = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  double s = 0.0;
-  if (slot < 24)
-    for (int b = grp; b < nblocks; b += 8) s += partials[static_cast<size_t>(b) * 24 + slot];
-  part[grp][slot] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (slot < 24) {
+    int b = grp;
+    for (; b + 96 < nblocks; b += 128) {
+      s0 += partials[static_cast<size_t>(b) * 24 + slot];
+      s1 += partials[static_cast<size_t>(b + 32) * 24 + slot];
+      s2 += partials[static_cast<size_t>(b + 64) * 24 + slot];
+      s3 += partials[static_cast<size_t>(b + 96) * 24 + slot];
+    }
+    for (; b < nblocks; b += 32) s0 += partials[static_cast<size_t>(b) * 24 + slot];
+  }
+  part[grp][slot] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (threadIdx.x < 24) {
     double tot = part[0][threadIdx.x];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) tot += part[g][threadIdx.x];
+    for (int g = 1; g < 32; ++g) tot += part[g][threadIdx.x];
     pack_out[threadIdx.x] = tot;
   }
 }
@@ -413,38 +470,57 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const uint8_t* __restric
   }
 }
 
+// ---- kernel table ------------------------------------------------------------------------------
+typedef void (*SweepFn)(Planes, SweepParams, double*);
+
+template <int MODE, int DEPTH, typename ST, int KIND>
+SweepFn pick_loss(bool loss) {
+  return loss ? sweep_kernel<MODE, DEPTH, ST, KIND, true> : sweep_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+SweepFn pick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? pick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss)
+                               : pick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
 template <int MODE, int DEPTH>
-hipError_t launch_sweep_store(int store, const Planes& pl, const SweepParams& prm, double* partials,
-                              int grid, hipStream_t stream) {
-  if (store == 0)
-    hipLaunchKernelGGL((sweep_kernel<MODE, DEPTH, double>), dim3(grid), dim3(kBlock), 0, stream, pl,
-                       prm, partials);
-  else
-    hipLaunchKernelGGL((sweep_kernel<MODE, DEPTH, float>), dim3(grid), dim3(kBlock), 0, stream, pl,
-                       prm, partials);
-  return hipGetLastError();
+SweepFn pick_store(int store, int kind, bool loss) {
+  return store == 0 ? pick_kind<MODE, DEPTH, double>(kind, loss) : pick_kind<MODE, DEPTH, float>(kind, loss);
+}
+SweepFn pick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return pick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return pick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return pick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return pick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return pick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return pick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
 }
 
 }  // namespace
 
 int points_per_lane(int store) { return store == 0 ? 2 : 4; }
 
-hipError_t launch_sweep(int mode, int depth, int store, const Planes& pl, const SweepParams& prm,
+// Resident blocks per CU of the selected sweep kernel (the grid is sized to exactly one resident
+// wave of blocks; the grid-stride loop spreads the vectors evenly over them).
+hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks) {
+  SweepFn fn = pick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(fn), kBlock, 0);
+}
+
+hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& pl, const SweepParams& prm,
                         double* partials, int grid, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
-  switch (mode * 2 + depth) {
-    case 0: return launch_sweep_store<MODE_ROT, DEPTH_UNIFORM>(store, pl, prm, partials, grid, stream);
-    case 1: return launch_sweep_store<MODE_ROT, DEPTH_PER_MATCH>(store, pl, prm, partials, grid, stream);
-    case 2: return launch_sweep_store<MODE_TRAN, DEPTH_UNIFORM>(store, pl, prm, partials, grid, stream);
-    case 3: return launch_sweep_store<MODE_TRAN, DEPTH_PER_MATCH>(store, pl, prm, partials, grid, stream);
-    case 4: return launch_sweep_store<MODE_RT, DEPTH_UNIFORM>(store, pl, prm, partials, grid, stream);
-    case 5: return launch_sweep_store<MODE_RT, DEPTH_PER_MATCH>(store, pl, prm, partials, grid, stream);
-  }
-  return hipErrorInvalidValue;
+  SweepFn fn = pick(mode, depth, store, kind, prm.delta > 0.0);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, pl, prm, partials);
+  return hipGetLastError();
 }
 
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, pack_out);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out);
   return hipGetLastError();
 }
 

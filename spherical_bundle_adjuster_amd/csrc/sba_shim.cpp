@@ -97,7 +97,11 @@ struct sba_problem {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cus = 0;
-  int blocks_per_cu = 4;
+  int blocks_per_cu_cap = 8;   // SBA_BLOCKS_PER_CU: upper bound on resident blocks per CU used
+  int kind = SBA_KERNEL_FACTORED;
+  int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
+  double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
+  int last_mode = 0;
 
   size_t n = 0;
   int store = SBA_STORE_F64;
@@ -162,11 +166,19 @@ int alloc_planes(sba_problem* p, size_t n, bool with_d12, int store) {
   return SBA_OK;
 }
 
-int grid_for(const sba_problem* p) {
+// One resident wave of blocks: min(blocks needed, CUs x resident blocks per CU of this kernel).
+int grid_for(sba_problem* p, int mode, int depth_mode, bool loss, int* grid) {
   const size_t ppt = static_cast<size_t>(sba::points_per_lane(p->store));
   const size_t nvec = (p->n + ppt - 1) / ppt;
   const size_t want = (nvec + sba::kBlock - 1) / sba::kBlock;
-  return static_cast<int>(std::min<size_t>(want, static_cast<size_t>(p->max_grid)));
+  int& occ = p->occ_cache[mode][depth_mode][p->store][p->kind][loss ? 1 : 0];
+  if (occ == 0) {
+    int b = 0;
+    SBA_HIP_TRY(sba::sweep_blocks_per_cu(mode, depth_mode, p->store, p->kind, loss, &b));
+    occ = std::max(1, std::min(b, p->blocks_per_cu_cap));
+  }
+  *grid = static_cast<int>(std::min<size_t>(want, static_cast<size_t>(std::min(p->max_grid, p->num_cus * occ))));
+  return SBA_OK;
 }
 
 int check_args(const sba_problem* p, int mode, int depth_mode, const double* rot, const double* tran) {
@@ -198,6 +210,11 @@ void make_params(const sba_problem* p, int depth_mode, const double rot[3], cons
   prm->n = p->n;
 }
 
+void make_frame(sba_problem* p, int mode, const double rot[3]) {
+  sba::factored_frame(rot, p->frame_B, p->frame_J);
+  p->last_mode = mode;
+}
+
 // Enqueue one sweep + finalize (+ all-reduce) on the problem's stream; pack_dev holds the result.
 int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepParams& prm) {
   sba::Planes pl;
@@ -207,9 +224,11 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   }
   pl.d1 = p->dplane[0];
   pl.d2 = p->dplane[1];
-  const int grid = grid_for(p);
+  int grid = 0;
+  int rc0 = grid_for(p, mode, depth_mode, prm.delta > 0.0, &grid);
+  if (rc0) return rc0;
   if (p->ev_sweep0) SBA_HIP_TRY(hipEventRecord(p->ev_sweep0, p->stream));
-  SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, pl, prm, p->partials, grid, p->stream));
+  SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, p->partials, grid, p->stream));
   if (p->ev_sweep1) SBA_HIP_TRY(hipEventRecord(p->ev_sweep1, p->stream));
   SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, p->stream));
   if (p->comm) {
@@ -226,11 +245,15 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   return SBA_OK;
 }
 
+// D2H of the reduced device pack; the factored kernel's moments are mapped to the SBA_PACK_* layout.
 int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
   SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, p->pack_dev, SBA_PACK_SIZE * sizeof(double),
                              hipMemcpyDeviceToHost, p->stream));
   SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-  std::memcpy(pack, p->pack_host, SBA_PACK_SIZE * sizeof(double));
+  if (p->kind == SBA_KERNEL_FACTORED && p->last_mode != SBA_MODE_TRAN)
+    sba::moments_to_normal_pack(true, p->last_mode == SBA_MODE_RT, p->frame_B, p->frame_J, p->pack_host, pack);
+  else
+    std::memcpy(pack, p->pack_host, SBA_PACK_SIZE * sizeof(double));
   return SBA_OK;
 }
 
@@ -276,15 +299,19 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   p->num_cus = prop.multiProcessorCount;
   if (const char* env = std::getenv("SBA_BLOCKS_PER_CU")) {
     const int v = std::atoi(env);
-    if (v >= 1 && v <= 32) p->blocks_per_cu = v;
+    if (v >= 1 && v <= 8) p->blocks_per_cu_cap = v;
   }
+  if (const char* env = std::getenv("SBA_KERNEL")) {
+    if (std::strcmp(env, "explicit") == 0) p->kind = SBA_KERNEL_EXPLICIT;
+  }
+  std::memset(p->occ_cache, 0, sizeof(p->occ_cache));
   if (stream) {
     p->stream = static_cast<hipStream_t>(stream);
   } else {
     SBA_HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     p->own_stream = true;
   }
-  p->max_grid = std::max(1, p->num_cus * p->blocks_per_cu);
+  p->max_grid = std::max(1, p->num_cus * 8);
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->partials),
                         static_cast<size_t>(p->max_grid) * sba::kPackSize * sizeof(double)));
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->pack_dev), 32 * sizeof(double)));
@@ -378,6 +405,13 @@ int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const vo
   return upload_common(p, left_xyz_dev, right_xyz_dev, d12_dev, n, store, true);
 }
 
+int sba_problem_set_kernel(sba_problem* p, int kind) {
+  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  if (kind != SBA_KERNEL_FACTORED && kind != SBA_KERNEL_EXPLICIT) return fail(SBA_ERR_INVALID_ARG, "bad kernel kind %d", kind);
+  p->kind = kind;
+  return SBA_OK;
+}
+
 int sba_problem_size(const sba_problem* p, size_t* n) {
   if (!p || !n) return fail(SBA_ERR_INVALID_ARG, "null argument");
   *n = p->n;
@@ -393,6 +427,7 @@ int sba_problem_eval_pack(sba_problem* p, int mode, int depth_mode, const double
   SBA_HIP_TRY(hipSetDevice(p->device));
   sba::SweepParams prm;
   make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);
+  make_frame(p, mode, rot);
   rc = enqueue_sweep(p, mode, depth_mode, prm);
   if (rc) return rc;
   return fetch_pack(p, pack);
@@ -426,6 +461,7 @@ int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const doubl
   SBA_HIP_TRY(hipSetDevice(p->device));
   sba::SweepParams prm;
   make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);
+  make_frame(p, mode, rot);
   while (p->sweep_events.size() < static_cast<size_t>(2 * repeat)) {
     hipEvent_t e;
     SBA_HIP_TRY(hipEventCreate(&e));

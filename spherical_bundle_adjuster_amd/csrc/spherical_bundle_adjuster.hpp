@@ -1,0 +1,67 @@
+// Host-side C++ mirror of the reference's `spherical_bundle_adjuster` class
+// (reference spherical_bundle_adjuster.hpp:15-58): same constructor, set_omp and do_bundle_adjustment,
+// so the call sequence of main/main.cpp:29-32 compiles unchanged.  The Ceres-backed private
+// `solve_problem` is replaced by calls into the C-ABI (include/sba_hip.h); nothing here touches Ceres.
+//
+// Out of scope on this path: SURF/FLANN matching.  The reference hard-wires
+// `spherical_surf fm; fm.do_all(...)` (spherical_bundle_adjuster.cpp:264-266); here the matcher is a
+// pluggable callable with the same `do_all` signature, and `do_bundle_adjustment_from_matches` enters
+// right after it, with the matched key-points the reference's matchers return.
+#pragma once
+#include <array>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/sba_hip.h"
+#include "sba_types.hpp"
+
+class spherical_bundle_adjuster {
+ public:
+  // do_all(im_left, im_right, left_key, right_key, match_size, match_output, total_key_num)
+  // -- the signature shared by spherical_surf / equi2cube_surf / feature_matcher
+  //    (reference spherical_surf.hpp:13, equi2cube_surf.hpp:13, feature_matcher.hpp:37)
+  using matcher_fn = std::function<void(const cv::Mat&, const cv::Mat&, std::vector<cv::KeyPoint>&,
+                                        std::vector<cv::KeyPoint>&, int&, cv::Mat&, int&)>;
+
+  spherical_bundle_adjuster(double roll = 0, double pitch = 0, double yaw = 0, double tx = 0,
+                            double ty = 0, double tz = 0, double d = 0)
+      : expected_roll(roll), expected_pitch(pitch), expected_yaw(yaw), expected_tx(tx),
+        expected_ty(ty), expected_tz(tz), expected_d(d) {}
+  ~spherical_bundle_adjuster();
+
+  void set_omp(int num_proc);
+  void do_bundle_adjustment(const cv::Mat& im_left, const cv::Mat& im_right);
+
+  // ---- additions of this build (not in the reference) ------------------------------------------------
+  void set_matcher(matcher_fn fn) { matcher = std::move(fn); }
+  void set_device(int hip_device) { device = hip_device; }
+  void set_log_path(const std::string& path) { log_path = path; }   // default "log.txt" (.cpp:349)
+  // Everything after the matcher: pixel -> sphere, initial values, three-stage solve, log row.
+  // Returns 0 or a negative SBA_ERR_* (message via sba_last_error()).
+  int do_bundle_adjustment_from_matches(const std::vector<cv::KeyPoint>& left_key,
+                                        const std::vector<cv::KeyPoint>& right_key, int match_size,
+                                        int im_width, int im_height);
+  struct result {
+    double rot[3] = {0, 0, 0};    // angle-axis, radians (init_rot after solve_problem)
+    double tran[3] = {0, 0, 0};   // init_tran after solve_problem
+    int match_size = 0;
+    sba_lm_summary rot_stage{}, tran_stage{};
+    double depth_stage_cost = 0;
+  };
+  const result& last_result() const { return res; }
+
+ private:
+  // reference spherical_bundle_adjuster.hpp:37-43 with ceres::Solver::Options -> sba_lm_options
+  int solve_problem(sba_lm_options& opt, std::vector<cv::Point3d>& key_point_left_rect,
+                    std::vector<cv::Point3d>& key_point_right_rect, double* init_rot, double* init_tran,
+                    std::vector<std::array<double, 2>>& init_d, int match_num);
+
+  double expected_roll, expected_pitch, expected_yaw, expected_tx, expected_ty, expected_tz, expected_d;
+  int num_proc = 1;
+  int device = 0;
+  std::string log_path = "log.txt";
+  matcher_fn matcher;
+  sba_problem* problem = nullptr;
+  result res;
+};

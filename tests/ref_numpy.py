@@ -75,3 +75,25 @@ def normal_equations(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, delta=1.0, d12=Non
         sw += w
         nout += 1.0 if (delta > 0 and s > delta * delta) else 0.0
     return H, g, cost, sw, nout
+
+
+def d_rotated_d_w_mp(w, p, digits=50):
+    """50-digit reference of d(R(w) p)/dw (Rodrigues on the unit axis, differentiated by mpmath)."""
+    import mpmath as mp
+    mp.mp.dps = digits
+    w = [mp.mpf(float(x)) for x in w]
+    p = [mp.mpf(float(x)) for x in p]
+
+    def rotated(*ww):
+        th = mp.sqrt(sum(x * x for x in ww))
+        k = [x / th for x in ww]
+        kxp = [k[1] * p[2] - k[2] * p[1], k[2] * p[0] - k[0] * p[2], k[0] * p[1] - k[1] * p[0]]
+        kp = sum(a * b for a, b in zip(k, p))
+        return [p[i] * mp.cos(th) + kxp[i] * mp.sin(th) + k[i] * kp * (1 - mp.cos(th)) for i in range(3)]
+    J = np.zeros((3, 3))
+    for i in range(3):
+        for j in range(3):
+            order = [0, 0, 0]
+            order[j] = 1
+            J[i, j] = float(mp.diff(lambda a, b, c: rotated(a, b, c)[i], tuple(w), tuple(order)))
+    return J

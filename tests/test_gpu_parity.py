@@ -14,9 +14,12 @@ pytestmark = pytest.mark.gpu
 MODES = [api.MODE_ROT, api.MODE_TRAN, api.MODE_RT]
 
 
-@pytest.fixture(scope="module")
-def problem():
+@pytest.fixture(scope="module", params=[api.KERNEL_FACTORED, api.KERNEL_EXPLICIT], ids=["factored", "explicit"])
+def problem(request):
+    """Every parity test runs against both sweep kernels: the factored (moment) form and the explicit
+    per-match Jacobian form must each match the oracle."""
     p = api.Problem(0)
+    p.set_kernel(request.param)
     yield p
     p.close()
 
@@ -57,14 +60,18 @@ def test_pointwise_golden_fixtures(problem):
         got = problem.eval(mode, z["rot"][i], z["tran"][i], float(z["d1"][i]), float(z["d2"][i]), 0.0)   # no loss
         e, J = z["e"][i], z["J"][i]
         scale = max(np.abs(J.T @ J).max(), 1e-300)
-        assert np.abs(got.H - J.T @ J).max() <= 1e-13 * scale, (z["case"][i], mode)
-        assert np.abs(got.g - J.T @ e).max() <= 1e-13 * max(np.abs(J.T @ e).max(), scale), (z["case"][i], mode)
+        # The fixtures carry the Ceres formula's own derivative noise (~eps/theta) just above its small-angle
+        # threshold (tests/test_host_rotation_cpu.py); the device kernels are compared up to that noise.
+        th = float(np.linalg.norm(z["rot"][i]))
+        tol = 1e-13 + (0.0 if th * th <= np.finfo(float).eps else 8 * np.finfo(float).eps / th)
+        assert np.abs(got.H - J.T @ J).max() <= tol * scale, (z["case"][i], mode)
+        assert np.abs(got.g - J.T @ e).max() <= tol * max(np.abs(J.T @ e).max(), scale), (z["case"][i], mode)
         assert abs(got.cost - 0.5 * e @ e) <= 1e-14 * max(e @ e, 1e-300)
         # with Huber(1): cost = rho/2, weight = rho'
         goth = problem.eval(mode, z["rot"][i], z["tran"][i], float(z["d1"][i]), float(z["d2"][i]), 1.0)
         rho = z["rho"][i]
         assert abs(goth.cost - 0.5 * rho[0]) <= 4e-16 * max(rho[0], 1e-300) * 8
-        assert np.abs(goth.H - rho[1] * (J.T @ J)).max() <= 1e-13 * scale
+        assert np.abs(goth.H - rho[1] * (J.T @ J)).max() <= tol * scale
 
 
 @pytest.mark.parametrize("delta", [0.0, 0.05, 1.0, 100.0])
@@ -186,6 +193,12 @@ def test_full_size_properties(oracle, n, gen, mode, dm):
     with api.Problem(0) as p:
         p.upload(c.x1, c.x2, d12)
         full = p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm)
+        # the two kernels (factored moments vs explicit per-match Jacobian) agree at full size
+        p.set_kernel(api.KERNEL_EXPLICIT)
+        full_explicit = p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm)
+        p.set_kernel(api.KERNEL_FACTORED)
+        assert np.abs(full - full_explicit).max() <= REL_TOL_F64 * np.abs(full).max()
+        assert full[23] == full_explicit[23]
         # determinism: the fixed-order reduction makes repeated sweeps bit-identical
         assert np.array_equal(full, p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm))
         # oracle on a bounded prefix + additivity over shards (the multi-GPU sharding identity)

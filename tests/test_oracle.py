@@ -164,7 +164,7 @@ def test_side_paths_basic(oracle):
     # Reference quirk (equi2cube.cpp:47-50, no clamp): for every EVEN cube size the bottom-face centre
     # (i = j = S/2) looks exactly at the south pole, theta = pi -> row = H, one row past the image.
     # The oracle (and the HIP kernel) clamp that single pixel to row H-1.
-    assert clamped == 1
+    assert clamped == 1 and int(H * np.arccos(-1.0) / np.pi) == H
     _, clamped_odd = oracle.equi2cube(im, S + 1)
     assert clamped_odd == 0
     assert np.array_equal(out[..., 2], (out[..., 0].astype(int) * 7 + out[..., 1].astype(int) * 3) % 251)
