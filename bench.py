@@ -87,6 +87,21 @@ def cpu_baseline(c, mode, per_match, sample, seconds):
             "optimised_cpu_value": hoisted}
 
 
+def pmc_traffic(kernel_sig: str, n: int):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, made by
+    tools/profile_round.sh + tools/summarize_profiles.py with the gfx950 FETCH_SIZE x2 correction).
+    PMC counters cannot be read from inside the timed process, so this is the profiled run of the SAME
+    command; returns None when no matching profile is committed."""
+    try:
+        d = json.loads((ROOT / "profiles" / "pmc_latest.json").read_text())
+        k = d["kernels"][kernel_sig]
+        if d["bench_line_under_trace"]["config"]["correspondences_per_gpu"] != n:
+            return None
+        return k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     import numpy as np
@@ -160,6 +175,8 @@ def main():
         total = a.n * world
         value = total * a.steps / elapsed
         achieved = a.n * bytes_per_eval / (sweep_ms * 1e-3) / 1e9
+        kernel_sig = (f"sweep_kernel<{mode}, {depth_mode}, {'double' if a.store == 'f64' else 'float'}, "
+                      f"{1 if a.kernel == 'explicit' else 0}, true>")
         out = {
             "metric": "residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -172,8 +189,10 @@ def main():
                        "bytes_per_eval": bytes_per_eval, "allreduce": transport, "kernel": a.kernel,
                        "step": "sweep + finalize + all-reduce(24 f64) + D2H(192 B) + host sync"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "sweep_kernel", "kernel_ms": sweep_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(kernel_sig, a.n),
+                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                           "of this command; FETCH_SIZE x2 per MI355X_MICROARCH.md)",
+                         "kernel": kernel_sig, "kernel_ms": sweep_ms,
                          "algorithmic_bytes_per_launch": a.n * bytes_per_eval},
             "kernel_only_evals_per_s": a.n / (sweep_ms * 1e-3),
             "device_step_ms": step_ms,

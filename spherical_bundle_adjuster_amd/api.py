@@ -83,8 +83,8 @@ def _to_ne(ne: cabi.NormalEq) -> NormalEquations:
 class Problem:
     """One shard of correspondences resident on one GPU (``sba_problem``)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
-        self._lib = cabi.load_library()
+    def __init__(self, device: int = 0, stream: int | None = None, lib=None):
+        self._lib = lib if lib is not None else cabi.load_library()
         self._h = C.c_void_p()
         cabi.check(self._lib, self._lib.sba_problem_create(C.byref(self._h), device, C.c_void_p(stream or 0)))
         self._hook_keepalive = None

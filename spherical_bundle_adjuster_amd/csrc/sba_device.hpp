@@ -33,7 +33,10 @@ struct Planes {
 };
 
 constexpr int kPackSize = 24;
-constexpr int kBlock = 256;
+#ifndef SBA_BLOCK
+#define SBA_BLOCK 256
+#endif
+constexpr int kBlock = SBA_BLOCK;   // threads per sweep block (multiple of 64)
 
 // Sweep: residual + Jacobian + Huber + reduction of every block's partial pack into
 // partials[grid][24]; then finalize() folds the partials in a fixed order into pack_out[24].

@@ -29,6 +29,10 @@
 #ifndef SBA_PARAMS_IN_LDS
 #define SBA_PARAMS_IN_LDS 0
 #endif
+#ifndef SBA_NT_LOADS
+#define SBA_NT_LOADS 1     // the once-read coordinate stream is loaded non-temporally (global_load ... nt):
+                           // measured +10-12 % sweep bandwidth on MI355X (profiles/r01_variants.md)
+#endif
 
 namespace sba {
 namespace {
@@ -90,17 +94,27 @@ struct VecRegs {
   static constexpr int PPT = Lanes<ST>::PPT;
   typename Lanes<ST>::vec c[6];        // x1.x x1.y x1.z x2.x x2.y x2.z
   double2 d1[PPT / 2], d2[PPT / 2];    // per-match depths (always f64)
+  template <typename V>
+  static __device__ __forceinline__ V stream_load(const V* ptr) {
+#if SBA_NT_LOADS
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 r = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ptr));
+    return *reinterpret_cast<const V*>(&r);
+#else
+    return *ptr;
+#endif
+  }
   __device__ __forceinline__ void load(const Planes& pl, size_t p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      c[k] = reinterpret_cast<const typename Lanes<ST>::vec*>(pl.x1[k])[p];
-      c[3 + k] = reinterpret_cast<const typename Lanes<ST>::vec*>(pl.x2[k])[p];
+      c[k] = stream_load(reinterpret_cast<const typename Lanes<ST>::vec*>(pl.x1[k]) + p);
+      c[3 + k] = stream_load(reinterpret_cast<const typename Lanes<ST>::vec*>(pl.x2[k]) + p);
     }
     if (DEPTH == DEPTH_PER_MATCH) {
 #pragma unroll
       for (int h = 0; h < PPT / 2; ++h) {
-        d1[h] = reinterpret_cast<const double2*>(pl.d1)[p * (PPT / 2) + h];
-        d2[h] = reinterpret_cast<const double2*>(pl.d2)[p * (PPT / 2) + h];
+        d1[h] = stream_load(reinterpret_cast<const double2*>(pl.d1) + p * (PPT / 2) + h);
+        d2[h] = stream_load(reinterpret_cast<const double2*>(pl.d2) + p * (PPT / 2) + h);
       }
     }
   }

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=30)
     ap.add_argument("--caps", default="8")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--libs", default="", help="comma-separated name=path of alternative libsba_hip builds to A/B")
     a = ap.parse_args()
     c = synthetic.full_rt(a.n)
     rows = []
@@ -26,10 +27,15 @@ def main():
               ("rot", api.MODE_ROT, api.DEPTH_UNIFORM, 48, 24), ("tran", api.MODE_TRAN, api.DEPTH_UNIFORM, 48, 24)]
     if a.quick:
         combos = combos[:1]
-    for cap in [int(x) for x in a.caps.split(",")]:
+    from spherical_bundle_adjuster_amd import _cabi
+    libs = [("default", None)]
+    for item in filter(None, a.libs.split(",")):
+        nm, path = item.split("=")
+        libs.append((nm, _cabi.load_library(path)))
+    for cap, (lname, lib) in [(int(x), l) for x in a.caps.split(",") for l in libs]:
         os.environ["SBA_BLOCKS_PER_CU"] = str(cap)
         for store, sname in ((api.STORE_F64, "f64"), (api.STORE_F32, "f32")):
-            with api.Problem(0) as p:
+            with api.Problem(0, lib=lib) as p:
                 p.upload(c.x1, c.x2, c.d12, store=store)
                 for kind, kname in ((api.KERNEL_FACTORED, "factored"), (api.KERNEL_EXPLICIT, "explicit")):
                     p.set_kernel(kind)
@@ -42,7 +48,7 @@ def main():
                             _, step, sweep = p.eval_timed(mode, c.rot_init, c.tran_init, depth_mode=dm, repeat=a.repeat)
                             best = min(best, sweep)
                         bpe = b64 if store == api.STORE_F64 else b32
-                        print(f"cap={cap} {sname} {kname:9s} {name:5s} sweep {best*1e3:8.1f} us  step {step*1e3:8.1f} us  "
+                        print(f"{lname:8s} cap={cap} {sname} {kname:9s} {name:5s} sweep {best*1e3:8.1f} us  step {step*1e3:8.1f} us  "
                               f"{a.n*bpe/best/1e6:8.0f} GB/s  {a.n/best/1e6:8.1f} Gevals/s", flush=True)
 
 
