@@ -223,13 +223,15 @@ int sba_expand_pack(int mode, const double pack[SBA_PACK_SIZE], sba_normal_eq* o
 int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], double tran[3],
                       double d1, double d2, const sba_lm_options* opt, sba_lm_summary* summary);
 
-/* d-only stage (spherical_bundle_adjuster.cpp:1004-1063): per match an independent bounded
- * 2-parameter LM on (d1_i, d2_i) with regularisers lambda*exp(-c*d); needs per-match depths
- * uploaded (they are the initial values) and updates them on the device.  d12_out (double[2n],
- * may be NULL) receives the result.                                                         */
-int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3],
-                             double lambda, double c, int max_iterations, double* d12_out,
-                             double* total_cost);
+/* d-only stage (spherical_bundle_adjuster.cpp:1004-1063, `Solve(opt, &problem_d, &summary)` at :197): ONE
+ * bounded trust-region problem over all per-match depth pairs (5 residuals per match: the reprojection
+ * 3-vector and lambda*exp(-c*d1), lambda*exp(-c*d2); no loss; lower bound 0; the reference uses lambda = c = 1).
+ * Needs per-match depths uploaded (they are the initial values, init_d) and updates them on the device, so a
+ * following SBA_DEPTH_PER_MATCH sweep sees the refined depths.  d12_out (double[2n], may be NULL) receives
+ * them in init_d layout.  opt NULL = defaults (huber_delta / tran_param are ignored).  Single-GPU in this
+ * release: returns SBA_ERR_UNSUPPORTED when a communicator or all-reduce hook is installed.               */
+int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
+                             double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary);
 
 /* ---- multi-GPU: one process (and one sba_problem) per GPU, correspondences sharded ------ */
 /* Option A: native RCCL.  Rank 0 calls sba_comm_unique_id, ships the 128 bytes to the other

@@ -147,6 +147,18 @@ def lm_solve(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, d12=None, options: LmOptio
     return rot, tran, s, rc
 
 
+def depth_solve(x1, x2, rot, tran, d12, lam=1.0, c=1.0, options: LmOptions | None = None):
+    """d-only stage (reference .cpp:1004-1063) as one bounded trust-region problem; returns (d12, summary, rc)."""
+    x1, x2 = _f64(x1).reshape(-1, 3), _f64(x2).reshape(-1, 3)
+    d = _f64(d12).reshape(-1, 2).copy()
+    o = options if options is not None else default_options()
+    s = LmSummary()
+    lib().orc_depth_solve.restype = C.c_int
+    rc = lib().orc_depth_solve(_p(x1), _p(x2), C.c_size_t(x1.shape[0]), _p(_f64(rot)), _p(_f64(tran)),
+                               C.c_double(lam), C.c_double(c), _p(d), C.byref(o), C.byref(s))
+    return d, s, rc
+
+
 def keypoints_to_sphere(kp: np.ndarray, im_w: int, im_h: int) -> np.ndarray:
     kp = np.ascontiguousarray(kp)
     n = kp.shape[0]

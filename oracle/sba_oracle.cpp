@@ -473,6 +473,120 @@ int orc_lm_solve(int mode, int per_match_depth, const double* x1, const double* 
   }
 }
 
+// ---- d-only stage, spherical_bundle_adjuster.cpp:1004-1063 ------------------------------------------
+// One Ceres problem with N residual blocks of 5 residuals over the block's own 2 parameters d[0], d[1]
+// (AutoDiffCostFunction<d_only, 5, 2>, .cpp:1044), no loss (NULL, .cpp:1059), lower bound 0 on both
+// (.cpp:1060-1061), lambda = c = 1 (.cpp:1057-1058).  The Hessian is block diagonal, but it is ONE trust-region
+// problem: a single radius, a single accept/reject on the total cost, global convergence tests, Jacobi
+// scaling per parameter, and Plus() projects the candidate onto the bounds (Ceres' box-constraint handling;
+// max_num_line_search_step_size_iterations defaults to 0, so no projected line search).
+}  // extern "C"
+namespace {
+template <typename T>
+void depth_residuals(const double cam1[3], const double cam2[3], const double rot[3], const double tran[3],
+                     double lambda, double c, const T d[2], T res[5]) {
+  T r[3] = {T(rot[0]), T(rot[1]), T(rot[2])};
+  T t[3] = {T(tran[0]), T(tran[1]), T(tran[2])};
+  reprojection_residual(cam1, cam2, d, r, t, res);          // .cpp:1008-1027
+  res[3] = lambda * exp(T(-c) * d[0]);                        // .cpp:1028
+  res[4] = lambda * exp(T(-c) * d[1]);                        // .cpp:1029
+}
+}  // namespace
+extern "C" {
+
+int orc_depth_solve(const double* x1, const double* x2, size_t n, const double* rot, const double* tran,
+                    double lambda, double c, double* d12 /* in: initial, out: result */, const LmOptions* opt,
+                    LmSummary* sum) {
+  const LmOptions& o = *opt;
+  std::memset(sum, 0, sizeof(*sum));
+  std::vector<double> scale(2 * n), diag(2 * n), cand(2 * n), H(3 * n), g(2 * n);
+  auto evaluate = [&](const double* d, bool with_jac, double* gmax) {
+    long double cost = 0;
+    double gm = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (with_jac) {
+        typedef Dual<2> T;
+        T dd[2] = {T::var(d[2 * i], 0), T::var(d[2 * i + 1], 1)}, res[5];
+        depth_residuals(x1 + 3 * i, x2 + 3 * i, rot, tran, lambda, c, dd, res);
+        double h11 = 0, h12 = 0, h22 = 0, g1 = 0, g2 = 0, s = 0;
+        for (int k = 0; k < 5; ++k) {
+          h11 += res[k].d[0] * res[k].d[0]; h12 += res[k].d[0] * res[k].d[1]; h22 += res[k].d[1] * res[k].d[1];
+          g1 += res[k].d[0] * res[k].v; g2 += res[k].d[1] * res[k].v; s += res[k].v * res[k].v;
+        }
+        H[3 * i] = h11; H[3 * i + 1] = h12; H[3 * i + 2] = h22; g[2 * i] = g1; g[2 * i + 1] = g2;
+        cost += 0.5L * s;
+        // projected gradient norm for the bounded problem: |x - P(x - g)|_inf
+        gm = std::max(gm, std::fabs(d[2 * i] - std::max(d[2 * i] - g1, 0.0)));
+        gm = std::max(gm, std::fabs(d[2 * i + 1] - std::max(d[2 * i + 1] - g2, 0.0)));
+      } else {
+        double dd[2] = {d[2 * i], d[2 * i + 1]}, res[5], s = 0;
+        depth_residuals(x1 + 3 * i, x2 + 3 * i, rot, tran, lambda, c, dd, res);
+        for (int k = 0; k < 5; ++k) s += res[k] * res[k];
+        cost += 0.5L * s;
+      }
+    }
+    if (gmax) *gmax = gm;
+    sum->num_evaluations++;
+    return static_cast<double>(cost);
+  };
+  double gmax = 0;
+  double cost = evaluate(d12, true, &gmax);
+  sum->initial_cost = cost;
+  for (size_t k = 0; k < 2 * n; ++k) {
+    const double hkk = H[3 * (k / 2) + (k % 2 ? 2 : 0)];
+    scale[k] = o.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(hkk)) : 1.0;
+  }
+  double radius = o.initial_trust_region_radius, nu = 2.0;
+  bool reuse = false;
+  int invalid = 0;
+  auto done = [&](int term) { sum->termination = term; sum->final_cost = cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius; return 0; };
+  if (gmax <= o.gradient_tolerance) return done(2);
+  for (int it = 1;; ++it) {
+    if (it > o.max_num_iterations) return done(4);
+    if (radius < o.min_trust_region_radius) return done(5);
+    sum->num_iterations = it;
+    long double model = 0, step2 = 0, x2n = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const double s1 = scale[2 * i], s2 = scale[2 * i + 1];
+      const double h11 = s1 * H[3 * i] * s1, h12 = s1 * H[3 * i + 1] * s2, h22 = s2 * H[3 * i + 2] * s2;
+      const double g1 = s1 * g[2 * i], g2 = s2 * g[2 * i + 1];
+      if (!reuse) {
+        diag[2 * i] = std::min(std::max(h11, o.min_lm_diagonal), o.max_lm_diagonal);
+        diag[2 * i + 1] = std::min(std::max(h22, o.min_lm_diagonal), o.max_lm_diagonal);
+      }
+      const double a11 = h11 + diag[2 * i] / radius, a22 = h22 + diag[2 * i + 1] / radius, a12 = h12;
+      const double det = a11 * a22 - a12 * a12;
+      const double y1 = (-g1 * a22 + g2 * a12) / det, y2 = (-g2 * a11 + g1 * a12) / det;
+      model += -(g1 * y1 + g2 * y2) - 0.5 * (h11 * y1 * y1 + 2 * h12 * y1 * y2 + h22 * y2 * y2);
+      cand[2 * i] = std::max(d12[2 * i] + s1 * y1, 0.0);           // Plus + projection onto d >= 0
+      cand[2 * i + 1] = std::max(d12[2 * i + 1] + s2 * y2, 0.0);
+      for (int k = 0; k < 2; ++k) {
+        const double dd = cand[2 * i + k] - d12[2 * i + k];
+        step2 += static_cast<long double>(dd) * dd;
+        x2n += static_cast<long double>(d12[2 * i + k]) * d12[2 * i + k];
+      }
+    }
+    if (!(model > 0)) { if (++invalid >= 5) { done(6); return -6; } radius /= nu; nu *= 2; reuse = true; continue; }
+    invalid = 0;
+    const double cand_cost = evaluate(cand.data(), false, nullptr);
+    if (std::sqrt(static_cast<double>(step2)) <= o.parameter_tolerance * (std::sqrt(static_cast<double>(x2n)) + o.parameter_tolerance)) return done(3);
+    const double change = cost - cand_cost;
+    if (std::fabs(change) <= o.function_tolerance * cost) return done(1);
+    const double quality = change / static_cast<double>(model);
+    if (quality > o.min_relative_decrease) {
+      std::memcpy(d12, cand.data(), sizeof(double) * 2 * n);
+      cost = evaluate(d12, true, &gmax);
+      sum->num_successful_steps++;
+      const double q = 2.0 * quality - 1.0;
+      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
+      nu = 2.0; reuse = false;
+      if (gmax <= o.gradient_tolerance) return done(2);
+    } else {
+      radius /= nu; nu *= 2; reuse = true;
+    }
+  }
+}
+
 // ---- pixel -> unit sphere, spherical_bundle_adjuster.cpp:271-298 -------------------------------------
 void orc_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride, int im_w, int im_h, double* out) {
   const double w = im_w, h = im_h;

@@ -95,7 +95,8 @@ SIGNATURES = {
     "sba_expand_pack": (C.c_int, [C.c_int, _dp, C.POINTER(NormalEq)]),
     "sba_problem_solve": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                     C.POINTER(LmOptions), C.POINTER(LmSummary)]),
-    "sba_problem_solve_depths": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_double, C.c_int, _vp, _dp]),
+    "sba_problem_solve_depths": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_double, C.POINTER(LmOptions), _vp,
+                                           C.POINTER(LmSummary)]),
     "sba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sba_problem_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "sba_problem_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),

@@ -80,6 +80,12 @@ def _to_ne(ne: cabi.NormalEq) -> NormalEquations:
                            float(ne.cost), float(ne.sum_w), float(ne.n_outlier))
 
 
+def _summary(s: cabi.LmSummary) -> SolveSummary:
+    return SolveSummary(cabi.TERMINATION.get(s.termination, str(s.termination)), s.num_iterations,
+                        s.num_successful_steps, s.num_evaluations, s.initial_cost, s.final_cost,
+                        s.final_gradient_max_norm, s.final_radius, s.seconds_total, s.seconds_eval)
+
+
 class Problem:
     """One shard of correspondences resident on one GPU (``sba_problem``)."""
 
@@ -176,18 +182,18 @@ class Problem:
         s = cabi.LmSummary()
         cabi.check(self._lib, self._lib.sba_problem_solve(self._h, mode, depth_mode, _dptr(rot), _dptr(tran),
                                                           d1, d2, C.byref(opt), C.byref(s)))
-        return rot, tran, SolveSummary(cabi.TERMINATION.get(s.termination, str(s.termination)), s.num_iterations,
-                                       s.num_successful_steps, s.num_evaluations, s.initial_cost, s.final_cost,
-                                       s.final_gradient_max_norm, s.final_radius, s.seconds_total, s.seconds_eval)
+        return rot, tran, _summary(s)
 
-    def solve_depths(self, rot, tran, lam=1.0, c=1.0, max_iterations=50):
+    def solve_depths(self, rot, tran, lam=1.0, c=1.0, options: cabi.LmOptions | None = None):
+        """d-only stage: refines the uploaded per-match depths in place; returns (d12 (n,2), SolveSummary)."""
         rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
         out = np.zeros((self.size, 2))
-        cost = C.c_double(0)
+        opt = options if options is not None else default_lm_options()
+        s = cabi.LmSummary()
         cabi.check(self._lib, self._lib.sba_problem_solve_depths(self._h, _dptr(rot), _dptr(tran), lam, c,
-                                                                 max_iterations, out.ctypes.data_as(C.c_void_p),
-                                                                 C.byref(cost)))
-        return out, cost.value
+                                                                 C.byref(opt), out.ctypes.data_as(C.c_void_p),
+                                                                 C.byref(s)))
+        return out, _summary(s)
 
     # -- multi-GPU ------------------------------------------------------------------------------------
     def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes) -> None:

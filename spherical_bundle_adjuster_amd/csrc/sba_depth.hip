@@ -1,0 +1,144 @@
+// d-only stage on the device (reference spherical_bundle_adjuster.cpp:1004-1063, first stage of
+// solve_problem, .cpp:196-197).
+//
+// The reference builds ONE Ceres problem of N residual blocks (5 residuals: the reprojection 3-vector and the
+// two regularisers lambda*exp(-c*d), .cpp:1008-1029) over N private 2-parameter blocks with lower bound 0
+// (.cpp:1060-1061) and no loss (.cpp:1059).  The Hessian is block diagonal, so the damped system of every LM
+// iteration splits into N independent 2x2 solves -- but radius, accept/reject, Jacobi scaling and the convergence
+// tests are global.  depth_step_kernel therefore does, for every match in one pass: residuals + 5x2 Jacobian at the
+// current depths, the scaled damped 2x2 solve, the projected candidate, the candidate's cost, and contributes to
+// the six global reductions the host needs for Ceres' step logic (sba_shim.cpp: sba_problem_solve_depths).
+// One thread per match; 8-byte loads, lanes contiguous (512 B per wave instruction) -- trivially HBM-bound
+// (12 loads + 4 stores of 8 B per match and iteration).
+#include "sba_device.hpp"
+
+namespace sba {
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
+                                                        const double* __restrict__ d2,
+                                                        double* __restrict__ c1, double* __restrict__ c2,
+                                                        double* __restrict__ sc1, double* __restrict__ sc2,
+                                                        double* __restrict__ dg1, double* __restrict__ dg2,
+                                                        DepthParams P, double* __restrict__ partials) {
+  __shared__ double red[4][8];
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gmax = 0;
+  const double cl = P.c * P.lambda;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < P.n; i += stride) {
+    const double x = static_cast<const ST*>(pl.x1[0])[i], y = static_cast<const ST*>(pl.x1[1])[i],
+                 z = static_cast<const ST*>(pl.x1[2])[i];
+    const double u = static_cast<const ST*>(pl.x2[0])[i], v = static_cast<const ST*>(pl.x2[1])[i],
+                 w = static_cast<const ST*>(pl.x2[2])[i];
+    const double a = d1[i], b = d2[i];
+    // q = R x1 ; e = b x2 - a q + t                                                   (.cpp:1008-1027)
+    const double q0 = P.R[0] * x + P.R[1] * y + P.R[2] * z;
+    const double q1 = P.R[3] * x + P.R[4] * y + P.R[5] * z;
+    const double q2 = P.R[6] * x + P.R[7] * y + P.R[8] * z;
+    const double e0 = b * u - a * q0 + P.t[0], e1 = b * v - a * q1 + P.t[1], e2 = b * w - a * q2 + P.t[2];
+    const double r4 = P.lambda * exp(-P.c * a), r5 = P.lambda * exp(-P.c * b);       // .cpp:1028-1029
+    cost += 0.5 * (e0 * e0 + e1 * e1 + e2 * e2 + r4 * r4 + r5 * r5);
+    // J = [[-q, x2], [-c r4, 0], [0, -c r5]]
+    const double j41 = -P.c * r4, j52 = -P.c * r5;
+    const double qq = q0 * q0 + q1 * q1 + q2 * q2, qx = q0 * u + q1 * v + q2 * w, xx = u * u + v * v + w * w;
+    const double qe = q0 * e0 + q1 * e1 + q2 * e2, xe = u * e0 + v * e1 + w * e2;
+    const double h11 = qq + j41 * j41, h12 = -qx, h22 = xx + j52 * j52;
+    const double g1 = -qe + j41 * r4, g2 = xe + j52 * r5;
+    // projected gradient norm of the bounded problem: |x - P(x - g)|_inf
+    gmax = fmax(gmax, fmax(fabs(a - fmax(a - g1, 0.0)), fabs(b - fmax(b - g2, 0.0))));
+    double s1, s2;
+    if (P.first_iteration) {
+      s1 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h11)) : 1.0;
+      s2 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h22)) : 1.0;
+      sc1[i] = s1; sc2[i] = s2;
+    } else {
+      s1 = sc1[i]; s2 = sc2[i];
+    }
+    const double H11 = s1 * h11 * s1, H12 = s1 * h12 * s2, H22 = s2 * h22 * s2, G1 = s1 * g1, G2 = s2 * g2;
+    double D1, D2;
+    if (P.reuse_diagonal) {
+      D1 = dg1[i]; D2 = dg2[i];
+    } else {
+      D1 = fmin(fmax(H11, P.min_diagonal), P.max_diagonal);
+      D2 = fmin(fmax(H22, P.min_diagonal), P.max_diagonal);
+      dg1[i] = D1; dg2[i] = D2;
+    }
+    const double A11 = H11 + D1 / P.radius, A22 = H22 + D2 / P.radius, A12 = H12;
+    const double det = A11 * A22 - A12 * A12;
+    const double y1 = (-G1 * A22 + G2 * A12) / det, y2 = (-G2 * A11 + G1 * A12) / det;
+    model += -(G1 * y1 + G2 * y2) - 0.5 * (H11 * y1 * y1 + 2.0 * H12 * y1 * y2 + H22 * y2 * y2);
+    const double na = fmax(a + s1 * y1, 0.0), nb = fmax(b + s2 * y2, 0.0);   // Plus + projection onto d >= 0
+    c1[i] = na; c2[i] = nb;
+    step2 += (na - a) * (na - a) + (nb - b) * (nb - b);
+    x2n += a * a + b * b;
+    const double f0 = nb * u - na * q0 + P.t[0], f1 = nb * v - na * q1 + P.t[1], f2 = nb * w - na * q2 + P.t[2];
+    const double f4 = P.lambda * exp(-P.c * na), f5 = P.lambda * exp(-P.c * nb);
+    cand_cost += 0.5 * (f0 * f0 + f1 * f1 + f2 * f2 + f4 * f4 + f5 * f5);
+    (void)cl;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double r[6] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),
+                       wave_max(gmax)};
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) red[wave][k] = r[k];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = red[0][threadIdx.x];
+    for (int wv = 1; wv < 4; ++wv) s = threadIdx.x == 5 ? fmax(s, red[wv][5]) : s + red[wv][threadIdx.x];
+    partials[static_cast<size_t>(blockIdx.x) * 8 + threadIdx.x] = s;
+  }
+}
+
+// [nblocks][8] -> out[8]: sums of slots 0..4 and the max of slot 5, in a fixed order.
+__global__ __launch_bounds__(256) void depth_finalize_kernel(const double* __restrict__ partials, int nblocks,
+                                                             double* __restrict__ out) {
+  __shared__ double part[32][8];
+  const int slot = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  double s = 0.0;
+  if (slot < 6)
+    for (int b = grp; b < nblocks; b += 32) {
+      const double v = partials[static_cast<size_t>(b) * 8 + slot];
+      s = slot == 5 ? fmax(s, v) : s + v;
+    }
+  part[grp][slot] = s;
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double tot = part[0][threadIdx.x];
+    for (int g = 1; g < 32; ++g) tot = threadIdx.x == 5 ? fmax(tot, part[g][5]) : tot + part[g][threadIdx.x];
+    out[threadIdx.x] = tot;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
+                             double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
+                             const DepthParams& prm, double* partials, int grid, double* out8,
+                             hipStream_t stream) {
+  if (grid > 0) {
+    if (store == 0)
+      hipLaunchKernelGGL((depth_step_kernel<double>), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1,
+                         sc2, dg1, dg2, prm, partials);
+    else
+      hipLaunchKernelGGL((depth_step_kernel<float>), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1,
+                         sc2, dg1, dg2, prm, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, out8);
+  return hipGetLastError();
+}
+
+}  // namespace sba

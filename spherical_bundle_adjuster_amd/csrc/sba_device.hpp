@@ -55,17 +55,25 @@ hipError_t launch_d12_to_planes(const double* d12, size_t n, size_t first, doubl
 hipError_t launch_planes_to_d12(const double* d1, const double* d2, size_t n, double* d12,
                                 hipStream_t stream);
 
-// d-only stage: per match bounded 2-parameter LM (spherical_bundle_adjuster.cpp:1004-1063).
+// d-only stage (spherical_bundle_adjuster.cpp:1004-1063): one LM iteration of the global bounded problem.
 struct DepthParams {
   double R[9];
   double t[3];
   double lambda, c;
-  int max_iterations;
+  double radius;
+  double min_diagonal, max_diagonal;
+  int first_iteration;   // compute and store the Jacobi scaling
+  int reuse_diagonal;    // previous step was rejected: keep the stored LM diagonal
+  int jacobi_scaling;
+  int pad_;
   unsigned long long n;
 };
-hipError_t launch_depth_solve(int store, const Planes& pl, double* d1, double* d2,
-                              const DepthParams& prm, double* cost_partials, int grid,
-                              hipStream_t stream);
+// out8: [0] cost at d, [1] model cost change, [2] cost at candidate, [3] |step|^2, [4] |d|^2, [5] projected
+// gradient max-norm at d.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.
+hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
+                             double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
+                             const DepthParams& prm, double* partials, int grid, double* out8,
+                             hipStream_t stream);
 
 // pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
 hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride_bytes, double im_w,

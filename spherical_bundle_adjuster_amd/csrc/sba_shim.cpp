@@ -560,9 +560,117 @@ int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr) {
 
 // ---- callers / data formats either side of the path ----------------------------------------------
 int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
-                             double c, int max_iterations, double* d12_out, double* total_cost) {
-  (void)p; (void)rot; (void)tran; (void)lambda; (void)c; (void)max_iterations; (void)d12_out; (void)total_cost;
-  return fail(SBA_ERR_UNSUPPORTED, "sba_problem_solve_depths: d-only stage not built yet");
+                             double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary) {
+  if (!p || !rot || !tran) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  if (!p->has_d12 && p->n > 0) return fail(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
+  if (p->comm || p->hook) return fail(SBA_ERR_UNSUPPORTED, "d-only stage is single-GPU in this release");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  sba_lm_options o;
+  if (opt) o = *opt; else sba::lm_default_options(&o);
+  sba_lm_summary local;
+  sba_lm_summary* sum = summary ? summary : &local;
+  std::memset(sum, 0, sizeof(*sum));
+  const auto t_start = std::chrono::steady_clock::now();
+  const size_t n = p->n, elems = std::max<size_t>(p->plane_elems, 2);
+
+  // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, 8 results
+  double* work = nullptr;
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&work), 6 * elems * sizeof(double)));
+  double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
+         *dg2 = work + 5 * elems;
+  const int grid = static_cast<int>(std::min<size_t>((n + 255) / 256, static_cast<size_t>(p->num_cus) * 8));
+  double *partials = nullptr, *out_dev = nullptr;
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&partials), static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), 8 * sizeof(double)));
+  auto cleanup = [&]() { (void)hipFree(work); (void)hipFree(partials); (void)hipFree(out_dev); };
+
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+  sba::DepthParams prm;
+  double G[27];
+  sba::rotation_and_derivatives(rot, prm.R, G);
+  for (int i = 0; i < 3; ++i) prm.t[i] = tran[i];
+  prm.lambda = lambda; prm.c = c;
+  prm.min_diagonal = o.min_lm_diagonal; prm.max_diagonal = o.max_lm_diagonal;
+  prm.jacobi_scaling = o.jacobi_scaling; prm.pad_ = 0; prm.n = n;
+
+  double* cur1 = p->dplane[0];
+  double* cur2 = p->dplane[1];
+  double radius = o.initial_trust_region_radius, nu = 2.0;
+  bool reuse = false, first = true;
+  int invalid = 0, rc_final = SBA_OK;
+  double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto step = [&]() -> int {   // one device pass at the current depths
+    prm.radius = radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
+    SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                       out_dev, p->stream));
+    SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    std::memcpy(out, p->pack_host, sizeof(out));
+    sum->num_evaluations++;
+    first = false;
+    return SBA_OK;
+  };
+  auto finish = [&](int term, double cost, double gmax) {
+    sum->termination = term; sum->final_cost = cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius;
+    sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  };
+
+  for (int it = 1;; ++it) {
+    int rc = step();
+    if (rc) { cleanup(); return rc; }
+    const double cost = out[0], model = out[1], cand_cost = out[2], gmax = out[5];
+    if (it == 1) {
+      sum->initial_cost = cost;
+      if (!std::isfinite(cost)) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
+    }
+    // Ceres checks the gradient tolerance after every successful step (and at iteration 0): the gradient at the
+    // current point arrives with this pass.
+    if (!reuse && gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cost, gmax); break; }
+    if (it > o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cost, gmax); break; }
+    if (radius < o.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, cost, gmax); break; }
+    sum->num_iterations = it;
+    if (!(model > 0.0)) {
+      if (++invalid >= 5) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
+      radius /= nu; nu *= 2.0; reuse = true;
+      continue;
+    }
+    invalid = 0;
+    if (std::sqrt(out[3]) <= o.parameter_tolerance * (std::sqrt(out[4]) + o.parameter_tolerance)) {
+      finish(SBA_TERM_CONVERGENCE_PARAMETER, cost, gmax); break;
+    }
+    const double change = cost - cand_cost;
+    if (std::fabs(change) <= o.function_tolerance * cost) { finish(SBA_TERM_CONVERGENCE_FUNCTION, cost, gmax); break; }
+    const double quality = change / model;
+    if (quality > o.min_relative_decrease) {
+      std::swap(cur1, c1); std::swap(cur2, c2);     // the candidate planes become the current depths
+      sum->num_successful_steps++;
+      const double q = 2.0 * quality - 1.0;
+      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
+      nu = 2.0; reuse = false;
+    } else {
+      radius /= nu; nu *= 2.0; reuse = true;
+    }
+  }
+  // the problem's depth planes must end up holding the result
+  if (cur1 != p->dplane[0]) {
+    SBA_HIP_TRY(hipMemcpyAsync(p->dplane[0], cur1, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    SBA_HIP_TRY(hipMemcpyAsync(p->dplane[1], cur2, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  }
+  if (d12_out && n > 0) {
+    double* aos = nullptr;
+    SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aos), 2 * n * sizeof(double)));
+    SBA_HIP_TRY(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos, p->stream));
+    SBA_HIP_TRY(hipMemcpyAsync(d12_out, aos, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    SBA_HIP_TRY(hipFree(aos));
+  }
+  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  cleanup();
+  if (rc_final != SBA_OK) return fail(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
+  return SBA_OK;
 }
 
 static int require_device(int device) {

@@ -108,10 +108,10 @@ int spherical_bundle_adjuster::solve_problem(sba_lm_options& opt, std::vector<cv
 
   // stage 1: d-only (.cpp:196-197) -- per-match bounded depth refinement, lambda = c = 1 (.cpp:1057-1058)
   if (match_num > 0) {
-    rc = sba_problem_solve_depths(problem, init_rot, init_tran, 1.0, 1.0, opt.max_num_iterations,
-                                  reinterpret_cast<double*>(init_d.data()), &res.depth_stage_cost);
-    if (rc == SBA_ERR_UNSUPPORTED) rc = SBA_OK;   // stage not built yet: depths stay at expected_d
+    rc = sba_problem_solve_depths(problem, init_rot, init_tran, 1.0, 1.0, &opt,
+                                  reinterpret_cast<double*>(init_d.data()), &res.depth_stage);
     if (rc) return rc;
+    report("d-only", res.depth_stage);
   }
   // stages 2 and 3 use init_d[0][0] and init_d[1][0] for EVERY match (.cpp:941-942, :998-999)
   const double d1 = match_num > 0 ? init_d[0][0] : 0.0;

@@ -46,8 +46,7 @@ class spherical_bundle_adjuster {
     double rot[3] = {0, 0, 0};    // angle-axis, radians (init_rot after solve_problem)
     double tran[3] = {0, 0, 0};   // init_tran after solve_problem
     int match_size = 0;
-    sba_lm_summary rot_stage{}, tran_stage{};
-    double depth_stage_cost = 0;
+    sba_lm_summary depth_stage{}, rot_stage{}, tran_stage{};
   };
   const result& last_result() const { return res; }
 

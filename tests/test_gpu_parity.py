@@ -219,3 +219,38 @@ def test_full_size_properties(oracle, n, gen, mode, dm):
         # and the solve stage converges to it within the noise level
         r, t, s = p.solve(mode, c.rot_init, c.tran_init, depth_mode=dm)
         assert s.termination.startswith("CONVERGENCE") and np.abs(r - c.rot_true).max() < 5e-3
+
+
+# ---- d-only stage (first stage of solve_problem) ----------------------------------------------------------
+@pytest.mark.parametrize("n,store", [(1, api.STORE_F64), (65, api.STORE_F64), (5000, api.STORE_F64),
+                                     (5000, api.STORE_F32), (200001, api.STORE_F64)])
+def test_depth_stage_matches_oracle(oracle, n, store):
+    c = synthetic.full_rt(n, seed=300 + n)
+    d0 = np.full((n, 2), 3.0)
+    x1, x2 = (c.x1, c.x2) if store == api.STORE_F64 else (c.x1.astype(np.float32).astype(np.float64),
+                                                          c.x2.astype(np.float32).astype(np.float64))
+    dref, sref, rc = oracle.depth_solve(x1, x2, c.rot_init, c.tran_init, d0)
+    assert rc == 0
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, d0, store=store)
+        d, s = p.solve_depths(c.rot_init, c.tran_init)
+        assert (s.num_iterations, s.num_successful_steps) == (sref.num_iterations, sref.num_successful_steps)
+        assert s.termination == {1: "CONVERGENCE_FUNCTION", 2: "CONVERGENCE_GRADIENT", 3: "CONVERGENCE_PARAMETER",
+                                 4: "NO_CONVERGENCE"}[sref.termination]
+        assert np.abs(d - dref).max() <= 1e-9 * max(1.0, np.abs(dref).max()) and (d >= 0).all()
+        assert abs(s.final_cost - sref.final_cost) <= 1e-10 * sref.final_cost
+        # the refined depths stay on the device for the following stages
+        got = p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        ref = oracle.evaluate(2, x1, x2, c.rot_init, c.tran_init, d12=dref)
+        assert_normal_eq_close(got, ref, 1e-8, "after depth stage")
+
+
+def test_depth_stage_errors():
+    c = synthetic.rotation_only(10, seed=1)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2)                       # no depths
+        with pytest.raises(api.SbaError):
+            p.solve_depths(c.rot_init, c.tran_init)
+        p.upload(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 2)))
+        d, s = p.solve_depths(c.rot_init, c.tran_init)
+        assert d.shape == (0, 2) and s.termination == "CONVERGENCE_GRADIENT"

@@ -170,3 +170,22 @@ def test_side_paths_basic(oracle):
     assert np.array_equal(out[..., 2], (out[..., 0].astype(int) * 7 + out[..., 1].astype(int) * 3) % 251)
     # top face centre looks at the north pole (row 0), bottom face at the south pole
     assert out[S // 2, 4 * S + S // 2, 0] <= 1 and out[S // 2, 5 * S + S // 2, 0] >= H - 2
+
+
+def test_depth_stage_oracle(oracle):
+    """d-only stage restatement (.cpp:1004-1063): with the true R|t and clean data the depths are recovered up to
+    the bias of the lambda*exp(-c*d) regularisers; bounds are respected; a start at the optimum stops at once."""
+    c = synthetic.full_rt(300, seed=71, sigma=0.0, outlier_fraction=0.0)
+    d, s, rc = oracle.depth_solve(c.x1, c.x2, c.rot_true, c.tran_true, np.full((300, 2), 4.0))
+    assert rc == 0 and s.termination in (1, 2, 3) and s.final_cost < s.initial_cost
+    assert np.median(np.abs(d - c.d12)) < 0.05 and (d >= 0).all()
+    # regulariser only (x1 = x2 = 0 direction impossible on the sphere, so use tiny lambda): pure reprojection fit
+    d2, s2, rc = oracle.depth_solve(c.x1, c.x2, c.rot_true, c.tran_true, np.full((300, 2), 4.0), lam=1e-9)
+    assert rc == 0 and np.abs(d2 - c.d12).max() < 1e-3 * c.d12.max()
+    # outliers push some depths onto the bound d = 0
+    c = synthetic.full_rt(500, seed=6)
+    d3, s3, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, np.ones((500, 2)))
+    assert rc == 0 and d3.min() == 0.0 and (d3 >= 0).all()
+    # restart from the result: converges without moving
+    d4, s4, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, d3)
+    assert rc == 0 and s4.num_successful_steps <= 1 and np.abs(d4 - d3).max() < 1e-3
