@@ -214,6 +214,13 @@ int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const doubl
                            int repeat, double pack[SBA_PACK_SIZE], double* mean_step_ms,
                            double* mean_sweep_ms);
 
+/* `steps` complete, host-synchronous sweeps in a row -- each one exactly what an LM iteration costs (launch,
+ * reduction, all-reduce if installed, result on the host before the next launch) -- without a language binding
+ * between them.  Returns the last pack and the wall-clock seconds of the loop.                               */
+int sba_problem_eval_steps(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                           const double tran[3], double d1, double d2, double huber_delta, int steps,
+                           double pack[SBA_PACK_SIZE], double* seconds);
+
 /* Host-only: expand a pack into the 6x6 system (no device needed).                         */
 int sba_expand_pack(int mode, const double pack[SBA_PACK_SIZE], sba_normal_eq* out);
 

@@ -92,6 +92,8 @@ SIGNATURES = {
                                         C.c_double, _dp]),
     "sba_problem_eval_timed": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                          C.c_double, C.c_int, _dp, _dp, _dp]),
+    "sba_problem_eval_steps": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
+                                         C.c_double, C.c_int, _dp, _dp]),
     "sba_expand_pack": (C.c_int, [C.c_int, _dp, C.POINTER(NormalEq)]),
     "sba_problem_solve": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                     C.POINTER(LmOptions), C.POINTER(LmSummary)]),

@@ -173,6 +173,15 @@ class Problem:
                                                                C.byref(step_ms), C.byref(sweep_ms)))
         return pack, step_ms.value, sweep_ms.value
 
+    def eval_steps(self, mode, rot, tran, d1=1.0, d2=1.0, huber_delta=1.0, depth_mode=DEPTH_UNIFORM, steps: int = 1):
+        """`steps` host-synchronous sweeps in a row inside the library; returns (last pack, seconds of the loop)."""
+        rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
+        pack = np.zeros(cabi.PACK_SIZE)
+        sec = C.c_double(0)
+        cabi.check(self._lib, self._lib.sba_problem_eval_steps(self._h, mode, depth_mode, _dptr(rot), _dptr(tran),
+                                                               d1, d2, huber_delta, steps, _dptr(pack), C.byref(sec)))
+        return pack, sec.value
+
     # -- solve stage --------------------------------------------------------------------------------
     def solve(self, mode, rot, tran, d1=1.0, d2=1.0, depth_mode=DEPTH_UNIFORM, options: cabi.LmOptions | None = None):
         """LM solve; returns (rot, tran, SolveSummary).  Inputs are not modified."""

@@ -33,6 +33,7 @@ struct Planes {
 };
 
 constexpr int kPackSize = 24;
+constexpr int kRow = 32;   // doubles per block-partial row (256 B: two whole 128-byte lines, 24 used)
 #ifndef SBA_BLOCK
 #define SBA_BLOCK 256
 #endif
@@ -40,9 +41,22 @@ constexpr int kBlock = SBA_BLOCK;   // threads per sweep block (multiple of 64)
 
 // Sweep: residual + Jacobian + Huber + reduction of every block's partial pack into
 // partials[grid][24]; then finalize() folds the partials in a fixed order into pack_out[24].
+// Where a sweep leaves its result.  ticket == nullptr: only partials[grid][kRow] are written and
+// launch_finalize() must follow.  Otherwise the last-arriving block folds the partials into pack_dev[24] and, if
+// pack_host != nullptr (device-visible address of mapped pinned memory, >= 26 doubles), also stores the pack there
+// followed by `seq` at pack_host[24] (as a 64-bit integer) for the host to poll.  ticket: 9 counters, one per
+// 64-byte line (ticket[16*k]), zero before the first launch; the kernel re-zeroes them.
+struct SweepOut {
+  double* partials;
+  double* pack_dev;
+  double* pack_host;
+  unsigned int* ticket;
+  unsigned long long seq;
+};
+
 // kind: 0 = factored (moment pack, host applies J_l), 1 = explicit per-match Jacobian (SBA_PACK layout).
 hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& pl, const SweepParams& prm,
-                        double* partials, int grid, hipStream_t stream);
+                        const SweepOut& out, int grid, hipStream_t stream);
 hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream);
 

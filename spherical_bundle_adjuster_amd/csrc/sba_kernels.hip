@@ -275,12 +275,13 @@ __device__ __forceinline__ void consume(const VecRegs<ST, DEPTH>& r, const Sweep
 }
 
 template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
-__global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams prm,
-                                                      double* __restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams prm, SweepOut out) {
+  double* __restrict__ partials = out.partials;
   constexpr int NACC = AccMap<MODE, KIND>::N;
   constexpr int PPT = Lanes<ST>::PPT;
-  // One LDS object: [0, 48) the staged R|t state (SBA_PARAMS_IN_LDS), then the cross-wave scratch.
-  __shared__ double lds[48 + (kBlock / 64) * 24];
+  // One LDS object: [0, 48) the staged R|t state (SBA_PARAMS_IN_LDS) / the "I am last" word, then the
+  // cross-wave scratch (4 x 24), reused by the fused final fold (kBlock/16 x 24).
+  __shared__ double lds[48 + (kBlock / 16) * 24];
   double* wave_out = lds + 48;
   const int tid = threadIdx.x;
 #if SBA_PARAMS_IN_LDS
@@ -335,11 +336,97 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams pr
     }
   }
   __syncthreads();
-  if (tid < 24) {
-    double s = wave_out[tid];
+  // Block partial: one 256-byte row (24 sums + 8 zeros), stored by lanes 0..31 of wave 0 in ONE wave instruction
+  // so that both 128-byte lines of the row are written whole.
+  if (out.ticket == nullptr) {          // two-kernel mode: finalize_kernel folds the rows after the kernel boundary
+    if (tid < kRow) {
+      double s = 0.0;
+      if (tid < 24) {
+        s = wave_out[tid];
 #pragma unroll
-    for (int wv = 1; wv < kBlock / 64; ++wv) s += wave_out[wv * 24 + tid];
-    partials[static_cast<size_t>(blockIdx.x) * 24 + tid] = s;
+        for (int wv = 1; wv < kBlock / 64; ++wv) s += wave_out[wv * 24 + tid];
+      }
+      partials[static_cast<size_t>(blockIdx.x) * kRow + tid] = s;
+    }
+    return;
+  }
+
+  // ---- fused final reduction: the block that arrives last folds all rows (fixed order => the result does not
+  // depend on which block that is) and publishes the pack.  Hand-off (cdna_hip_programming.md Guideline 16,
+  // write-through form): sc1 row stores -> the storing wave's vmcnt(0) -> relaxed agent-scope ticket;
+  // the reducer acquires at agent scope once, then reads.  Tickets are hierarchical: blocks with equal
+  // blockIdx % 8 (observed to share an XCD; a speed assumption only) count on their own word, the last of each
+  // group counts on the top word -- 8 short queues instead of one long one.
+  if (tid < 64) {                        // wave 0
+    bool last = false;
+    if (tid < kRow) {
+      double s = 0.0;
+      if (tid < 24) {
+        s = wave_out[tid];
+#pragma unroll
+        for (int wv = 1; wv < kBlock / 64; ++wv) s += wave_out[wv * 24 + tid];
+      }
+      __hip_atomic_store(&partials[static_cast<size_t>(blockIdx.x) * kRow + tid], s, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);                                  // global_store ... sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      const unsigned g = blockIdx.x & 7u, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
+      const unsigned in_group = (gridDim.x - g + 7u) / 8u;                           // blocks b with b % 8 == g
+      if (__hip_atomic_fetch_add(out.ticket + 16 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+          in_group - 1)
+        last = __hip_atomic_fetch_add(out.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      lds[47] = last ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  if (lds[47] == 0.0) return;
+  {
+    // 16 slot pairs x NG groups of blocks; every thread issues up to 12 independent 16-byte loads before it adds
+    // (the rows were just written by other XCDs: each round trip costs ~2 us, so memory-level parallelism, not
+    // instruction count, sets the length of this tail).
+    const int nblocks = static_cast<int>(gridDim.x);
+    constexpr int NG = kBlock / 16;                       // 16 groups of blocks
+    const int pair = tid & 15, grp = tid >> 4;
+    double sx = 0.0, sy = 0.0;
+    if (pair < 12) {
+      const double2* src = reinterpret_cast<const double2*>(partials) + pair;   // row stride = 16 double2
+      for (int b0 = grp; b0 < nblocks; b0 += 12 * NG) {
+        double2 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          const int b = b0 + k * NG;
+          v[k] = b < nblocks ? src[static_cast<size_t>(b) * (kRow / 2)] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { sx += v[k].x; sy += v[k].y; }
+      }
+    }
+    double* fold_lds = wave_out;                         // the cross-wave scratch is free again: NG x 24 doubles
+    if (pair < 12) { fold_lds[grp * 24 + 2 * pair] = sx; fold_lds[grp * 24 + 2 * pair + 1] = sy; }
+    __syncthreads();
+    if (tid < 64) {                                      // wave 0 finishes alone: no further block barrier
+      if (tid < 24) {
+        double tot = fold_lds[tid];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) tot += fold_lds[g * 24 + tid];
+        out.pack_dev[tid] = tot;
+        if (out.pack_host) out.pack_host[tid] = tot;
+      }
+      if (tid < 9) out.ticket[16 * tid] = 0;             // counters ready for the next launch on this stream
+      if (out.pack_host) {
+        // publish to the host: this wave's pack stores, a system-scope release, then the sequence number
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(out.pack_host + 24), out.seq, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -354,12 +441,12 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict
   if (slot < 24) {
     int b = grp;
     for (; b + 96 < nblocks; b += 128) {
-      s0 += partials[static_cast<size_t>(b) * 24 + slot];
-      s1 += partials[static_cast<size_t>(b + 32) * 24 + slot];
-      s2 += partials[static_cast<size_t>(b + 64) * 24 + slot];
-      s3 += partials[static_cast<size_t>(b + 96) * 24 + slot];
+      s0 += partials[static_cast<size_t>(b) * kRow + slot];
+      s1 += partials[static_cast<size_t>(b + 32) * kRow + slot];
+      s2 += partials[static_cast<size_t>(b + 64) * kRow + slot];
+      s3 += partials[static_cast<size_t>(b + 96) * kRow + slot];
     }
-    for (; b < nblocks; b += 32) s0 += partials[static_cast<size_t>(b) * 24 + slot];
+    for (; b < nblocks; b += 32) s0 += partials[static_cast<size_t>(b) * kRow + slot];
   }
   part[grp][slot] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -485,7 +572,7 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const uint8_t* __restric
 }
 
 // ---- kernel table ------------------------------------------------------------------------------
-typedef void (*SweepFn)(Planes, SweepParams, double*);
+typedef void (*SweepFn)(Planes, SweepParams, SweepOut);
 
 template <int MODE, int DEPTH, typename ST, int KIND>
 SweepFn pick_loss(bool loss) {
@@ -525,11 +612,11 @@ hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool lo
 }
 
 hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& pl, const SweepParams& prm,
-                        double* partials, int grid, hipStream_t stream) {
+                        const SweepOut& out, int grid, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   SweepFn fn = pick(mode, depth, store, kind, prm.delta > 0.0);
   if (!fn) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, pl, prm, partials);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, stream, pl, prm, out);
   return hipGetLastError();
 }
 

@@ -114,7 +114,12 @@ struct sba_problem {
   double* partials = nullptr;  // [max_grid][24]
   int max_grid = 0;
   double* pack_dev = nullptr;  // 32 doubles
-  double* pack_host = nullptr; // pinned, 32 doubles
+  double* pack_host = nullptr; // pinned + mapped, 32 doubles ([24] = sequence number published by the kernel)
+  double* pack_host_dev = nullptr;  // device-visible address of pack_host
+  unsigned int* ticket = nullptr;   // arrival counter of the fused final reduction
+  unsigned long long seq = 0;       // sweeps launched with host publication
+  bool fused = true;                // SBA_FUSED=0: two-kernel mode (sweep + finalize_kernel + D2H copy)
+  bool published = false;           // the last enqueued sweep publishes to pack_host itself
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_events;        // eval_timed: brackets of each sweep launch
   hipEvent_t ev_sweep0 = nullptr, ev_sweep1 = nullptr;
@@ -227,10 +232,20 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   int grid = 0;
   int rc0 = grid_for(p, mode, depth_mode, prm.delta > 0.0, &grid);
   if (rc0) return rc0;
+  // Single-GPU: the sweep's last block publishes the pack to mapped host memory (no finalize kernel, no copy).
+  // With an all-reduce to follow, the fused reduction only fills pack_dev.
+  const bool collective = p->comm != nullptr || p->hook != nullptr;
+  sba::SweepOut out;
+  out.partials = p->partials;
+  out.pack_dev = p->pack_dev;
+  out.ticket = p->fused ? p->ticket : nullptr;
+  p->published = p->fused && !collective && grid > 0;
+  out.pack_host = p->published ? p->pack_host_dev : nullptr;
+  out.seq = p->published ? ++p->seq : 0;
   if (p->ev_sweep0) SBA_HIP_TRY(hipEventRecord(p->ev_sweep0, p->stream));
-  SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, p->partials, grid, p->stream));
+  SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, out, grid, p->stream));
   if (p->ev_sweep1) SBA_HIP_TRY(hipEventRecord(p->ev_sweep1, p->stream));
-  SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, p->stream));
+  if (!p->fused || grid == 0) SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, p->stream));
   if (p->comm) {
     Rccl& r = rccl();
     const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
@@ -245,11 +260,28 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   return SBA_OK;
 }
 
-// D2H of the reduced device pack; the factored kernel's moments are mapped to the SBA_PACK_* layout.
+// Wait for the reduced pack on the host; the factored kernel's moments are mapped to the SBA_PACK_* layout.
 int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
-  SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, p->pack_dev, SBA_PACK_SIZE * sizeof(double),
-                             hipMemcpyDeviceToHost, p->stream));
-  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->published) {
+    // The kernel stores the 24 doubles, fences at system scope, then stores the sequence number: poll it.
+    // A stream query every so often turns a device fault into an error instead of an endless spin.
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24);
+    for (unsigned long spins = 0; *flag != p->seq; ++spins) {
+      if ((spins & 0xfff) == 0xfff) {
+        const hipError_t q = hipStreamQuery(p->stream);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(SBA_ERR_HIP, "sweep failed on the device: %s", hipGetErrorString(q));
+        if (q == hipSuccess && *flag != p->seq)
+          return fail(SBA_ERR_HIP, "sweep finished without publishing its result");
+      }
+      __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  } else {
+    SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, p->pack_dev, SBA_PACK_SIZE * sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  }
   if (p->kind == SBA_KERNEL_FACTORED && p->last_mode != SBA_MODE_TRAN)
     sba::moments_to_normal_pack(true, p->last_mode == SBA_MODE_RT, p->frame_B, p->frame_J, p->pack_host, pack);
   else
@@ -313,11 +345,16 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   }
   p->max_grid = std::max(1, p->num_cus * 8);
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->partials),
-                        static_cast<size_t>(p->max_grid) * sba::kPackSize * sizeof(double)));
+                        static_cast<size_t>(p->max_grid) * sba::kRow * sizeof(double)));
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->pack_dev), 32 * sizeof(double)));
   SBA_HIP_TRY(hipMemset(p->pack_dev, 0, 32 * sizeof(double)));
   SBA_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->pack_host), 32 * sizeof(double),
-                            hipHostMallocDefault));
+                            hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(p->pack_host, 0, 32 * sizeof(double));
+  SBA_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->pack_host_dev), p->pack_host, 0));
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->ticket), 9 * 64));
+  SBA_HIP_TRY(hipMemset(p->ticket, 0, 9 * 64));
+  if (const char* env = std::getenv("SBA_FUSED")) p->fused = std::strcmp(env, "0") != 0;
   SBA_HIP_TRY(hipEventCreate(&p->ev0));
   SBA_HIP_TRY(hipEventCreate(&p->ev1));
   *out = p;
@@ -335,6 +372,7 @@ int sba_problem_destroy(sba_problem* p) {
   free_planes(p);
   if (p->partials) (void)hipFree(p->partials);
   if (p->pack_dev) (void)hipFree(p->pack_dev);
+  if (p->ticket) (void)hipFree(p->ticket);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -433,6 +471,27 @@ int sba_problem_eval_pack(sba_problem* p, int mode, int depth_mode, const double
   return fetch_pack(p, pack);
 }
 
+int sba_problem_eval_steps(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                           const double tran[3], double d1, double d2, double huber_delta, int steps,
+                           double pack[SBA_PACK_SIZE], double* seconds) {
+  int rc = check_args(p, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (!pack || steps < 1) return fail(SBA_ERR_INVALID_ARG, "bad pack/steps");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < steps; ++i) {
+    sba::SweepParams prm;
+    make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);   // the host-side R, dR/dw of every iteration
+    make_frame(p, mode, rot);
+    rc = enqueue_sweep(p, mode, depth_mode, prm);
+    if (rc) return rc;
+    rc = fetch_pack(p, pack);
+    if (rc) return rc;
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return SBA_OK;
+}
+
 int sba_expand_pack(int mode, const double pack[SBA_PACK_SIZE], sba_normal_eq* out) {
   if (!pack || !out) return fail(SBA_ERR_INVALID_ARG, "null argument");
   if (mode < SBA_MODE_ROT || mode > SBA_MODE_RT) return fail(SBA_ERR_INVALID_ARG, "bad mode %d", mode);
@@ -478,6 +537,7 @@ int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const doubl
   SBA_HIP_TRY(hipEventRecord(p->ev1, p->stream));
   rc = fetch_pack(p, pack);
   if (rc) return rc;
+  SBA_HIP_TRY(hipEventSynchronize(p->ev1));
   float ms = 0.f;
   SBA_HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   if (mean_step_ms) *mean_step_ms = static_cast<double>(ms) / repeat;

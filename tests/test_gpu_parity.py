@@ -254,3 +254,23 @@ def test_depth_stage_errors():
         p.upload(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 2)))
         d, s = p.solve_depths(c.rot_init, c.tran_init)
         assert d.shape == (0, 2) and s.termination == "CONVERGENCE_GRADIENT"
+
+
+def test_fused_and_two_kernel_reduction_agree(oracle, monkeypatch):
+    """SBA_FUSED=0 (sweep + finalize kernel + D2H copy) and the default fused last-block reduction with host
+    publication give the same pack (different but fixed fold orders: equal to rounding), each deterministic."""
+    c = synthetic.full_rt(300007, seed=404)
+    packs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SBA_FUSED", fused)
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, c.d12)
+            a = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            for _ in range(20):      # repeated launches reuse the arrival counter
+                assert np.array_equal(a, p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH))
+            b, _, _ = p.eval_timed(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, repeat=7)
+            assert np.array_equal(a, b)
+            packs[fused] = a
+    assert np.abs(packs["1"] - packs["0"]).max() <= 1e-13 * np.abs(packs["0"]).max()
+    ref = pack_from_eval(2, oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12))
+    assert np.abs(packs["1"] - ref).max() <= REL_TOL_F64 * np.abs(ref).max()

@@ -1,0 +1,70 @@
+"""GPU (-m gpu): the C++ mirror of the reference class (csrc/spherical_bundle_adjuster.cpp) driven through the CLI
+with the reference's argument contract (main/main.cpp:8-27), against the oracle's three-stage pipeline
+(pixel -> sphere, d-only, rot-only, tran-only with the init_d[0][0]/init_d[1][0] quirk)."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+from spherical_bundle_adjuster_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+SBA_MAIN = ROOT / "spherical_bundle_adjuster_amd" / "csrc" / "build" / "sba_main"
+
+
+def _sphere_to_pixels(x, W, H):
+    colat = np.arccos(np.clip(x[:, 2], -1, 1))
+    lon = np.mod(np.arctan2(x[:, 1], x[:, 0]), 2 * np.pi)
+    return lon / (2 * np.pi) * W, colat / np.pi * H
+
+
+def _write_keypoints(path, px, py, W, H):
+    kp = np.zeros((len(px), 7), dtype=np.float32)      # cv::KeyPoint records (28 B)
+    kp[:, 0], kp[:, 1] = px, py
+    with open(path, "wb") as f:
+        np.array([len(px), W, H, 0], dtype=np.int32).tofile(f)
+        kp.tofile(f)
+    return kp
+
+
+def test_cli_three_stage_pipeline(oracle, tmp_path):
+    assert SBA_MAIN.exists(), "build with make -C spherical_bundle_adjuster_amd/csrc"
+    W, H, n = 3840, 1920, 2048                          # config C1: ~2k matches between two ERP frames
+    c = synthetic.full_rt(n, seed=synthetic.BASE_SEED, sigma=2e-4, outlier_fraction=0.02)
+    lx, ly = _sphere_to_pixels(c.x1, W, H)
+    rx, ry = _sphere_to_pixels(c.x2, W, H)
+    kl = _write_keypoints(tmp_path / "left.kp", lx, ly, W, H)
+    kr = _write_keypoints(tmp_path / "right.kp", rx, ry, W, H)
+    deg = np.rad2deg(c.rot_init)
+    exp_d = 6.0
+    args = [str(SBA_MAIN), str(tmp_path / "left.kp"), str(tmp_path / "right.kp"), *(f"{v:.17g}" for v in deg),
+            *(f"{v:.17g}" for v in c.tran_init), f"{exp_d}"]
+    r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "rotation vector in degree" in r.stdout and "translation vector" in r.stdout and "Done." in r.stdout
+    row = (tmp_path / "log.txt").read_text().strip().split(",")
+    assert len(row) == 10 and int(row[9]) == n           # same 10 columns as the reference's log.txt (.cpp:348-354)
+    got_rot = np.deg2rad([float(v) for v in row[3:6]])
+    got_tran = np.array([float(v) for v in row[6:9]])
+
+    # oracle pipeline on the same key-points
+    x1 = oracle.keypoints_to_sphere(kl, W, H)
+    x2 = oracle.keypoints_to_sphere(kr, W, H)
+    rot0 = np.deg2rad(deg)                               # CLI passes degrees (main/main.cpp:20-22, .cpp:328)
+    d, _, rc = oracle.depth_solve(x1, x2, rot0, c.tran_init, np.full((n, 2), exp_d))
+    assert rc == 0
+    d1, d2 = d[0, 0], d[1, 0]                            # init_d[0][0], init_d[1][0] for every match
+    r1, t1, _, _ = oracle.lm_solve(0, x1, x2, rot0, c.tran_init, d1, d2)
+    r2, t2, _, _ = oracle.lm_solve(1, x1, x2, r1, t1, d1, d2)
+    # log.txt prints ~6 significant digits
+    assert np.abs(got_rot - r2).max() < 2e-6 * max(1, np.abs(r2).max()) + 1e-7
+    assert np.abs(got_tran - t2).max() < 2e-5 * max(1, np.abs(t2).max())
+
+
+def test_cli_usage_and_errors(tmp_path):
+    r = subprocess.run([str(SBA_MAIN)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "usage" in r.stdout     # the reference returns 0 on a usage error (main/main.cpp:11)
+    r = subprocess.run([str(SBA_MAIN), "nope", "nope", *["0"] * 7], capture_output=True, text=True, timeout=30)
+    assert r.returncode != 0
