@@ -253,6 +253,29 @@ int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
  * correspondences in either kernel's layout, so summing it across shards is exact).            */
 int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);
 
+/* ---- batched per-pair solve (BASELINE config C5: many ERP pairs, each its own two-view problem) ------- */
+/* The reference handles one image pair per process run (main/main.cpp:6-34); a batch holds `num_pairs`
+ * independent problems on one GPU: pair g owns correspondences [offsets[g], offsets[g+1]) of the
+ * concatenated arrays (same layouts as sba_problem_upload; offsets has num_pairs+1 entries, ragged and empty
+ * pairs allowed).  ONE kernel launch evaluates every pair at its own (rot, tran); sba_batch_solve runs one LM per
+ * pair in lock-step (same schedule as sba_problem_solve).  Pairs are independent, so across GPUs they are
+ * simply split between processes -- no collective.                                                        */
+typedef struct sba_batch sba_batch;
+int sba_batch_create(sba_batch** out, int device, void* stream);
+int sba_batch_destroy(sba_batch* b);
+int sba_batch_set_kernel(sba_batch* b, int kind);
+int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_xyz, const double* d12,
+                     const size_t* offsets, int num_pairs, int store);
+int sba_batch_size(const sba_batch* b, int* num_pairs, int* blocks_per_pair);
+/* rot, tran: double[num_pairs][3]; d1, d2: double[num_pairs] uniform depths per pair (NULL = 1.0; ignored with
+ * SBA_DEPTH_PER_MATCH); packs: double[num_pairs][SBA_PACK_SIZE].                                          */
+int sba_batch_eval(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                   const double* d1, const double* d2, double huber_delta, double* packs);
+/* rot / tran are updated in place per pair; summaries (sba_lm_summary[num_pairs]) and status
+ * (int[num_pairs], SBA_OK or SBA_ERR_NUMERIC per pair) may be NULL.                                        */
+int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,
+                    const double* d2, const sba_lm_options* opt, sba_lm_summary* summaries, int* status);
+
 /* ---- callers / data formats either side of the path ------------------------------------- */
 /* pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298).  keypoints: n records of
  * `stride_bytes` bytes whose first two floats are pt.x, pt.y (cv::KeyPoint: stride 28).

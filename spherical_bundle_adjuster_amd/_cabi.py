@@ -103,6 +103,14 @@ SIGNATURES = {
     "sba_problem_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "sba_problem_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "sba_problem_pack_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "sba_batch_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    "sba_batch_destroy": (C.c_int, [_vp]),
+    "sba_batch_set_kernel": (C.c_int, [_vp, C.c_int]),
+    "sba_batch_upload": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    "sba_batch_size": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sba_batch_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp]),
+    "sba_batch_solve": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(LmOptions),
+                                  C.POINTER(LmSummary), C.POINTER(C.c_int)]),
     "sba_keypoints_to_sphere": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),
     "sba_equi2cube": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "sba_equi2cube_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

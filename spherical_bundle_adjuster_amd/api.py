@@ -233,6 +233,90 @@ class Problem:
         return p.value or 0
 
 
+class Batch:
+    """Many independent two-view problems ("pairs") on one GPU (``sba_batch``; BASELINE config C5)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None, lib=None):
+        self._lib = lib if lib is not None else cabi.load_library()
+        self._h = C.c_void_p()
+        cabi.check(self._lib, self._lib.sba_batch_create(C.byref(self._h), device, C.c_void_p(stream or 0)))
+        self.num_pairs = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sba_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_kernel(self, kind: int) -> None:
+        cabi.check(self._lib, self._lib.sba_batch_set_kernel(self._h, kind))
+
+    def upload(self, left_xyz, right_xyz, offsets, d12=None, store: int = STORE_F64) -> None:
+        """left/right: (total, 3); offsets: (num_pairs+1,) row offsets of each pair; d12: (total, 2) or None."""
+        x1 = _f64(left_xyz).reshape(-1, 3)
+        x2 = _f64(right_xyz).reshape(-1, 3)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if off.ndim != 1 or off.size < 1 or int(off[-1]) > x1.shape[0] or x1.shape != x2.shape:
+            raise ValueError("bad offsets / array shapes")
+        dp = None
+        if d12 is not None:
+            d = _f64(d12).reshape(-1, 2)
+            if d.shape[0] != x1.shape[0]:
+                raise ValueError("d12 length differs")
+            dp = d.ctypes.data_as(C.c_void_p)
+        self.num_pairs = off.size - 1
+        cabi.check(self._lib, self._lib.sba_batch_upload(
+            self._h, x1.ctypes.data_as(C.c_void_p), x2.ctypes.data_as(C.c_void_p), dp,
+            off.ctypes.data_as(C.POINTER(C.c_size_t)), self.num_pairs, store))
+
+    @property
+    def blocks_per_pair(self) -> int:
+        n, b = C.c_int(0), C.c_int(0)
+        cabi.check(self._lib, self._lib.sba_batch_size(self._h, C.byref(n), C.byref(b)))
+        return b.value
+
+    def _pp(self, a, width):
+        if a is None:
+            return None, None
+        arr = _f64(a).reshape(self.num_pairs, width) if width > 1 else _f64(a).reshape(self.num_pairs)
+        return arr, _dptr(arr)
+
+    def eval(self, mode, rot, tran, d1=None, d2=None, huber_delta=1.0, depth_mode=DEPTH_UNIFORM) -> np.ndarray:
+        """rot, tran: (num_pairs, 3).  Returns packs (num_pairs, 24) in the SBA_PACK layout."""
+        rot, rp = self._pp(rot, 3)
+        tran, tp = self._pp(tran, 3)
+        d1a, d1p = self._pp(d1, 1)
+        d2a, d2p = self._pp(d2, 1)
+        packs = np.zeros((self.num_pairs, cabi.PACK_SIZE))
+        cabi.check(self._lib, self._lib.sba_batch_eval(self._h, mode, depth_mode, rp, tp, d1p, d2p, huber_delta,
+                                                       _dptr(packs)))
+        return packs
+
+    def solve(self, mode, rot, tran, d1=None, d2=None, depth_mode=DEPTH_UNIFORM, options: cabi.LmOptions | None = None):
+        """Per-pair LM in lock-step.  Returns (rot (B,3), tran (B,3), [SolveSummary], status (B,))."""
+        rot = _f64(rot).reshape(self.num_pairs, 3).copy()
+        tran = _f64(tran).reshape(self.num_pairs, 3).copy()
+        d1a, d1p = self._pp(d1, 1)
+        d2a, d2p = self._pp(d2, 1)
+        opt = options if options is not None else default_lm_options()
+        sums = (cabi.LmSummary * max(self.num_pairs, 1))()
+        status = np.zeros(max(self.num_pairs, 1), dtype=np.int32)
+        cabi.check(self._lib, self._lib.sba_batch_solve(self._h, mode, depth_mode, _dptr(rot), _dptr(tran), d1p, d2p,
+                                                        C.byref(opt), sums, status.ctypes.data_as(C.POINTER(C.c_int))))
+        return rot, tran, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
+
+
 def comm_unique_id() -> bytes:
     lib = cabi.load_library()
     buf = C.create_string_buffer(cabi.COMM_ID_BYTES)

@@ -1,0 +1,297 @@
+// Batched per-pair solve (BASELINE config C5: "256 ERP pairs x 50k matches each, per-pair LM"): the reference
+// would run main/main.cpp once per pair; here all pairs of a batch live in one set of planes, ONE launch
+// evaluates every pair at its own R|t, and one host LmSolver per pair advances in lock-step off that launch.
+// Pairs are independent: across GPUs they shard without any collective.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sba_internal.hpp"
+#include "sba_lm.hpp"
+#include "sba_rotation.hpp"
+
+struct sba_batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 0;
+  int kind = SBA_KERNEL_FACTORED;
+
+  int num_pairs = 0;
+  int store = SBA_STORE_F64;
+  bool has_d12 = false;
+  bool uploaded = false;
+  std::vector<size_t> n;            // matches per pair
+  std::vector<size_t> first_vec;    // first 16-byte vector of the pair inside the planes
+  size_t total_vecs = 0;
+  void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* dplane[2] = {nullptr, nullptr};
+  sba::PairDesc* desc_dev = nullptr;
+  sba::SweepParams* params_dev = nullptr;
+  sba::SweepParams* params_host = nullptr;   // pinned
+  double* partials = nullptr;
+  int bpp = 1;                                // blocks per pair
+  double* packs_dev = nullptr;
+  double* packs_host = nullptr;               // pinned
+};
+
+namespace {
+
+int free_batch_data(sba_batch* b) {
+  for (auto& c : b->coord) { if (c) SBA_TRY_HIP(hipFree(c)); c = nullptr; }
+  for (auto& d : b->dplane) { if (d) SBA_TRY_HIP(hipFree(d)); d = nullptr; }
+  if (b->desc_dev) SBA_TRY_HIP(hipFree(b->desc_dev));
+  if (b->params_dev) SBA_TRY_HIP(hipFree(b->params_dev));
+  if (b->params_host) SBA_TRY_HIP(hipHostFree(b->params_host));
+  if (b->partials) SBA_TRY_HIP(hipFree(b->partials));
+  if (b->packs_dev) SBA_TRY_HIP(hipFree(b->packs_dev));
+  if (b->packs_host) SBA_TRY_HIP(hipHostFree(b->packs_host));
+  b->desc_dev = nullptr; b->params_dev = nullptr; b->params_host = nullptr; b->partials = nullptr;
+  b->packs_dev = nullptr; b->packs_host = nullptr;
+  b->uploaded = false; b->num_pairs = 0; b->n.clear(); b->first_vec.clear();
+  return SBA_OK;
+}
+
+int check_batch_args(const sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  if (mode < SBA_MODE_ROT || mode > SBA_MODE_RT) return sba::set_error(SBA_ERR_INVALID_ARG, "bad mode %d", mode);
+  if (depth_mode != SBA_DEPTH_UNIFORM && depth_mode != SBA_DEPTH_PER_MATCH)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "bad depth_mode %d", depth_mode);
+  if (depth_mode == SBA_DEPTH_PER_MATCH && !b->has_d12)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "per-match depths requested but none were uploaded");
+  if (b->num_pairs > 0 && (!rot || !tran)) return sba::set_error(SBA_ERR_INVALID_ARG, "rot/tran must not be null");
+  return SBA_OK;
+}
+
+// One batched launch: pair g is evaluated at (rot[g], tran[g]) unless active[g] == 0.  packs_host then holds
+// the raw device packs (moment layout for the factored kernel).
+int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran, const double* d1,
+                 const double* d2, double huber_delta, const unsigned char* active) {
+  const int B = b->num_pairs;
+  for (int g = 0; g < B; ++g) {
+    const bool on = !active || active[g];
+    sba::make_sweep_params(on ? b->n[g] : 0, depth_mode, rot + 3 * g, tran + 3 * g, d1 ? d1[g] : 1.0,
+                           d2 ? d2[g] : 1.0, huber_delta, &b->params_host[g]);
+  }
+  SBA_TRY_HIP(hipMemcpyAsync(b->params_dev, b->params_host, sizeof(sba::SweepParams) * B, hipMemcpyHostToDevice,
+                             b->stream));
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
+  pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  SBA_TRY_HIP(sba::launch_batch_sweep(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
+                                      b->desc_dev, B, b->bpp, b->partials, b->packs_dev, b->stream));
+  SBA_TRY_HIP(hipMemcpyAsync(b->packs_host, b->packs_dev, sizeof(double) * 24 * B, hipMemcpyDeviceToHost, b->stream));
+  SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+  return SBA_OK;
+}
+
+void convert_pack(const sba_batch* b, int mode, const double rot[3], const double* raw, double* pack) {
+  if (b->kind == SBA_KERNEL_FACTORED && mode != SBA_MODE_TRAN) {
+    double Bm[9], J[9];
+    sba::factored_frame(rot, Bm, J);
+    sba::moments_to_normal_pack(true, mode == SBA_MODE_RT, Bm, J, raw, pack);
+  } else {
+    std::memcpy(pack, raw, sizeof(double) * 24);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sba_batch_create(sba_batch** out, int device, void* stream) {
+  if (!out) return sba::set_error(SBA_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  int count = 0;
+  const hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return sba::set_error(SBA_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                          e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= count) return sba::set_error(SBA_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, count);
+  SBA_TRY_HIP(hipSetDevice(device));
+  sba_batch* b = new sba_batch();
+  b->device = device;
+  hipDeviceProp_t prop;
+  SBA_TRY_HIP(hipGetDeviceProperties(&prop, device));
+  b->num_cus = prop.multiProcessorCount;
+  if (const char* env = std::getenv("SBA_KERNEL"))
+    if (std::strcmp(env, "explicit") == 0) b->kind = SBA_KERNEL_EXPLICIT;
+  if (stream) {
+    b->stream = static_cast<hipStream_t>(stream);
+  } else {
+    SBA_TRY_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->own_stream = true;
+  }
+  *out = b;
+  return SBA_OK;
+}
+
+int sba_batch_destroy(sba_batch* b) {
+  if (!b) return SBA_OK;
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->stream);
+  free_batch_data(b);
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return SBA_OK;
+}
+
+int sba_batch_set_kernel(sba_batch* b, int kind) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  if (kind != SBA_KERNEL_FACTORED && kind != SBA_KERNEL_EXPLICIT) return sba::set_error(SBA_ERR_INVALID_ARG, "bad kernel kind %d", kind);
+  b->kind = kind;
+  return SBA_OK;
+}
+
+int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_xyz, const double* d12,
+                     const size_t* offsets, int num_pairs, int store) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  if (num_pairs < 0 || (num_pairs > 0 && !offsets)) return sba::set_error(SBA_ERR_INVALID_ARG, "bad offsets / num_pairs");
+  if (store != SBA_STORE_F64 && store != SBA_STORE_F32) return sba::set_error(SBA_ERR_INVALID_ARG, "bad store %d", store);
+  for (int g = 0; g < num_pairs; ++g)
+    if (offsets[g + 1] < offsets[g]) return sba::set_error(SBA_ERR_INVALID_ARG, "offsets must be non-decreasing");
+  const size_t total = num_pairs > 0 ? offsets[num_pairs] - offsets[0] : 0;
+  if (total > 0 && (!left_xyz || !right_xyz)) return sba::set_error(SBA_ERR_INVALID_ARG, "null coordinate array");
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  int rc = free_batch_data(b);
+  if (rc) return rc;
+  b->num_pairs = num_pairs;
+  b->store = store;
+  b->has_d12 = d12 != nullptr;
+  // every pair starts on a whole vector; vectors are sized for the widest lane group (4 elements) so that the
+  // same offsets serve f64 (2 per vector) and f32 (4 per vector) planes, plus one spare vector for the tail load
+  const size_t ppt = static_cast<size_t>(sba::points_per_lane(store));
+  b->n.resize(num_pairs);
+  b->first_vec.resize(num_pairs);
+  size_t vec = 0, max_n = 0;
+  std::vector<sba::PairDesc> desc(num_pairs);
+  for (int g = 0; g < num_pairs; ++g) {
+    b->n[g] = offsets[g + 1] - offsets[g];
+    b->first_vec[g] = vec;
+    desc[g].first_vec = vec;
+    desc[g].n = b->n[g];
+    vec += (b->n[g] + ppt - 1) / ppt + 1;
+    max_n = std::max(max_n, b->n[g]);
+  }
+  b->total_vecs = vec + 1;
+  const size_t elems = b->total_vecs * ppt, esz = store == SBA_STORE_F64 ? 8 : 4;
+  for (auto& c : b->coord) {
+    SBA_TRY_HIP(hipMalloc(&c, elems * esz));
+    SBA_TRY_HIP(hipMemsetAsync(c, 0, elems * esz, b->stream));
+  }
+  if (d12)
+    for (auto& d : b->dplane) {
+      SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&d), elems * 8));
+      SBA_TRY_HIP(hipMemsetAsync(d, 0, elems * 8, b->stream));
+    }
+  if (num_pairs == 0) { b->uploaded = true; return SBA_OK; }
+
+  // blocks per pair: fill one resident wave of blocks over all pairs, never more than a pair can use
+  int occ = 1;
+  SBA_TRY_HIP(sba::batch_blocks_per_cu(SBA_MODE_RT, d12 ? SBA_DEPTH_PER_MATCH : SBA_DEPTH_UNIFORM, store, b->kind, true, &occ));
+  const size_t capacity = static_cast<size_t>(b->num_cus) * std::max(1, std::min(occ, 4));
+  const size_t need = (((max_n + ppt - 1) / ppt) + sba::kBlock - 1) / sba::kBlock;
+  b->bpp = static_cast<int>(std::max<size_t>(1, std::min<size_t>(std::max<size_t>(need, 1), std::max<size_t>(1, capacity / num_pairs))));
+  if (const char* env = std::getenv("SBA_BATCH_BPP")) { const int v = std::atoi(env); if (v >= 1 && v <= 1024) b->bpp = v; }
+
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->desc_dev), sizeof(sba::PairDesc) * num_pairs));
+  SBA_TRY_HIP(hipMemcpy(b->desc_dev, desc.data(), sizeof(sba::PairDesc) * num_pairs, hipMemcpyHostToDevice));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->params_dev), sizeof(sba::SweepParams) * num_pairs));
+  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->params_host), sizeof(sba::SweepParams) * num_pairs, hipHostMallocDefault));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->partials), sizeof(double) * sba::kRow * num_pairs * b->bpp));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->packs_dev), sizeof(double) * 24 * num_pairs));
+  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->packs_host), sizeof(double) * 24 * num_pairs, hipHostMallocDefault));
+
+  // stage the AoS arrays whole, then re-lay each pair out at its plane offset
+  const size_t base = offsets[0];
+  double* stage = nullptr;
+  if (total > 0) {
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&stage), total * 3 * sizeof(double)));
+    const double* src[2] = {left_xyz, right_xyz};
+    for (int side = 0; side < 2; ++side) {
+      SBA_TRY_HIP(hipMemcpyAsync(stage, src[side] + 3 * base, total * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      for (int g = 0; g < num_pairs; ++g)
+        SBA_TRY_HIP(sba::launch_aos_to_planes(stage + 3 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
+                                              b->coord[3 * side], b->coord[3 * side + 1], b->coord[3 * side + 2],
+                                              store, b->stream));
+      SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    }
+    if (d12) {
+      SBA_TRY_HIP(hipMemcpyAsync(stage, d12 + 2 * base, total * 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      for (int g = 0; g < num_pairs; ++g)
+        SBA_TRY_HIP(sba::launch_d12_to_planes(stage + 2 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
+                                              b->dplane[0], b->dplane[1], b->stream));
+      SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    }
+    SBA_TRY_HIP(hipFree(stage));
+  }
+  SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+  b->uploaded = true;
+  return SBA_OK;
+}
+
+int sba_batch_size(const sba_batch* b, int* num_pairs, int* blocks_per_pair) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  if (num_pairs) *num_pairs = b->num_pairs;
+  if (blocks_per_pair) *blocks_per_pair = b->bpp;
+  return SBA_OK;
+}
+
+int sba_batch_eval(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                   const double* d1, const double* d2, double huber_delta, double* packs) {
+  int rc = check_batch_args(b, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (b->num_pairs == 0) return SBA_OK;
+  if (!packs) return sba::set_error(SBA_ERR_INVALID_ARG, "packs is null");
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  rc = batch_launch(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, nullptr);
+  if (rc) return rc;
+  for (int g = 0; g < b->num_pairs; ++g) convert_pack(b, mode, rot + 3 * g, b->packs_host + 24 * g, packs + 24 * g);
+  return SBA_OK;
+}
+
+int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,
+                    const double* d2, const sba_lm_options* opt, sba_lm_summary* summaries, int* status) {
+  int rc = check_batch_args(b, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  const int B = b->num_pairs;
+  if (B == 0) return SBA_OK;
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  sba_lm_options o;
+  if (opt) o = *opt; else sba::lm_default_options(&o);
+  o.verbose = 0;   // 256 interleaved progress tables help nobody
+  std::vector<sba::LmSolver> solver(B);
+  std::vector<unsigned char> active(B, 1);
+  std::vector<double> qrot(3 * B), qtran(3 * B);
+  for (int g = 0; g < B; ++g) solver[g].start(mode, rot + 3 * g, tran + 3 * g, o);
+  int remaining = B;
+  while (remaining > 0) {
+    for (int g = 0; g < B; ++g)
+      for (int a = 0; a < 3; ++a) { qrot[3 * g + a] = solver[g].query_rot()[a]; qtran[3 * g + a] = solver[g].query_tran()[a]; }
+    rc = batch_launch(b, mode, depth_mode, qrot.data(), qtran.data(), d1, d2, o.huber_delta, active.data());
+    if (rc) return rc;
+    for (int g = 0; g < B; ++g) {
+      if (!active[g]) continue;
+      double pack[24];
+      convert_pack(b, mode, qrot.data() + 3 * g, b->packs_host + 24 * g, pack);
+      sba_normal_eq ne;
+      sba::expand_pack(mode, pack, &ne);
+      solver[g].feed(ne);
+      if (solver[g].done()) { active[g] = 0; --remaining; }
+    }
+  }
+  int failures = 0;
+  for (int g = 0; g < B; ++g) {
+    for (int a = 0; a < 3; ++a) { rot[3 * g + a] = solver[g].rot()[a]; tran[3 * g + a] = solver[g].tran()[a]; }
+    if (summaries) summaries[g] = solver[g].summary();
+    if (status) status[g] = solver[g].status();
+    if (solver[g].status() != SBA_OK) ++failures;
+  }
+  if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed (see per-pair status)", failures, B);
+  return SBA_OK;
+}
+
+}  // extern "C"

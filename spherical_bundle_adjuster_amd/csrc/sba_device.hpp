@@ -60,6 +60,18 @@ hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& 
 hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream);
 
+// Batched problems (config C5): pair g owns vectors [first_vec, first_vec + ceil(n/PPT)) of the shared planes and
+// params[g] (its own R|t; params[g].n = 0 skips the pair).  bpp blocks per pair; partials [num_pairs*bpp][kRow];
+// packs [num_pairs][24] in the selected kernel's layout.
+struct PairDesc {
+  unsigned long long first_vec;
+  unsigned long long n;
+};
+hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
+hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
+                              const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
+                              double* partials, double* packs, hipStream_t stream);
+
 // AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.
 hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void* px, void* py,
                                 void* pz, int store, hipStream_t stream);

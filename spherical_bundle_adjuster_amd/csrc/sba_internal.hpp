@@ -1,0 +1,26 @@
+// Internal helpers shared by the host-side sources of libsba_hip.so (not exported through the C-ABI header).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/sba_hip.h"
+#include "sba_device.hpp"
+
+namespace sba {
+
+// Records the message returned by sba_last_error() on this thread and returns `code`.
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Host-side per-sweep state from (rot, tran, depths, delta): SweepParams for the device, and the frame
+// (B, J) that maps the factored kernel's moments to normal equations.
+void make_sweep_params(size_t n, int depth_mode, const double rot[3], const double tran[3], double d1, double d2,
+                       double huber_delta, SweepParams* prm);
+
+}  // namespace sba
+
+#define SBA_TRY_HIP(expr)                                                                            \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return sba::set_error(SBA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                               \
+  } while (0)

@@ -430,6 +430,88 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams pr
   }
 }
 
+// ---- batched sweep: many independent two-view problems ("pairs") in ONE launch (BASELINE config C5) ------------
+// Block group g = blockIdx.x / bpp works on pair g with that pair's own R|t (params[g], wave-uniform address ->
+// scalar loads), blocks j = blockIdx.x % bpp of the group grid-stride over the pair's vectors.  Rows of block
+// partials are folded per pair by batch_finalize_kernel.  A pair with n == 0 (e.g. already converged) costs its
+// blocks only the row store.
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const SweepParams* __restrict__ params,
+                                                            const PairDesc* __restrict__ desc, int bpp,
+                                                            double* __restrict__ partials) {
+  constexpr int NACC = AccMap<MODE, KIND>::N;
+  constexpr int PPT = Lanes<ST>::PPT;
+  __shared__ double lds[(kBlock / 64) * 24];
+  double* wave_out = lds;
+  const int tid = threadIdx.x;
+  const unsigned pair = blockIdx.x / static_cast<unsigned>(bpp), j = blockIdx.x % static_cast<unsigned>(bpp);
+  const SweepParams* __restrict__ P = params + pair;
+  const size_t n = P->n, first = desc[pair].first_vec;
+  const size_t stride = static_cast<size_t>(bpp) * kBlock;
+
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  const size_t nfull = n / PPT;
+  size_t p = static_cast<size_t>(j) * kBlock + tid;
+  VecRegs<ST, DEPTH> cur, nxt;
+  if (p < nfull) cur.load(pl, first + p);
+  while (p < nfull) {
+    const size_t pn = p + stride;
+    if (pn < nfull) nxt.load(pl, first + pn);
+    consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, P, p, n, acc);
+    cur = nxt;
+    p = pn;
+  }
+  if (nfull * PPT != n && j == static_cast<unsigned>(bpp) - 1 && tid == kBlock - 1) {
+    cur.load(pl, first + nfull);
+    consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, P, nfull, n, acc);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const double s = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) wave_out[wave * 24 + AccMap<MODE, KIND>::slot(k)] = s;
+  }
+  if (NACC < 24 && tid < 24) {
+    bool used = false;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) used |= (AccMap<MODE, KIND>::slot(k) == tid);
+    if (!used) {
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64; ++wv) wave_out[wv * 24 + tid] = 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid < kRow) {
+    double s = 0.0;
+    if (tid < 24) {
+      s = wave_out[tid];
+#pragma unroll
+      for (int wv = 1; wv < kBlock / 64; ++wv) s += wave_out[wv * 24 + tid];
+    }
+    partials[static_cast<size_t>(blockIdx.x) * kRow + tid] = s;
+  }
+}
+
+// One wave per pair folds that pair's bpp rows (fixed order) into packs[pair][24].
+__global__ __launch_bounds__(64) void batch_finalize_kernel(const double* __restrict__ partials, int bpp,
+                                                            double* __restrict__ packs) {
+  const int pair = blockIdx.x, slot = threadIdx.x;
+  if (slot >= 24) return;
+  const double* rows = partials + static_cast<size_t>(pair) * bpp * kRow + slot;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = 0;
+  for (; b + 3 < bpp; b += 4) {
+    s0 += rows[static_cast<size_t>(b) * kRow];
+    s1 += rows[static_cast<size_t>(b + 1) * kRow];
+    s2 += rows[static_cast<size_t>(b + 2) * kRow];
+    s3 += rows[static_cast<size_t>(b + 3) * kRow];
+  }
+  for (; b < bpp; ++b) s0 += rows[static_cast<size_t>(b) * kRow];
+  packs[static_cast<size_t>(pair) * 24 + slot] = (s0 + s1) + (s2 + s3);
+}
+
 // Fold partials[nblocks][24] in a fixed order.  1024 threads = 32 slots x 32 groups: group g sums
 // blocks g, g+32, ... for its slot (4 independent chains so the loads pipeline), then the 32 groups are
 // summed serially per slot.  Independent of timing, so results are run-to-run identical.
@@ -599,9 +681,56 @@ SweepFn pick(int mode, int depth, int store, int kind, bool loss) {
   return nullptr;
 }
 
+// ---- batch kernel table (same template axes as the single-problem sweep) ---------------------------------------
+typedef void (*BatchFn)(Planes, const SweepParams*, const PairDesc*, int, double*);
+template <int MODE, int DEPTH, typename ST, int KIND>
+BatchFn bpick_loss(bool loss) {
+  return loss ? batch_sweep_kernel<MODE, DEPTH, ST, KIND, true> : batch_sweep_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+BatchFn bpick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? bpick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss)
+                               : bpick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
+template <int MODE, int DEPTH>
+BatchFn bpick_store(int store, int kind, bool loss) {
+  return store == 0 ? bpick_kind<MODE, DEPTH, double>(kind, loss) : bpick_kind<MODE, DEPTH, float>(kind, loss);
+}
+BatchFn bpick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return bpick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return bpick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return bpick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return bpick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return bpick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return bpick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
+}
+
 }  // namespace
 
 int points_per_lane(int store) { return store == 0 ? 2 : 4; }
+
+hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks) {
+  BatchFn fn = bpick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(fn), kBlock, 0);
+}
+
+hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
+                              const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
+                              double* partials, double* packs, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchFn fn = bpick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs) * bpp), dim3(kBlock), 0, stream, pl, params, desc,
+                     bpp, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(batch_finalize_kernel, dim3(num_pairs), dim3(64), 0, stream, partials, bpp, packs);
+  return hipGetLastError();
+}
 
 // Resident blocks per CU of the selected sweep kernel (the grid is sized to exactly one resident
 // wave of blocks; the grid-stride loop spreads the vectors evenly over them).

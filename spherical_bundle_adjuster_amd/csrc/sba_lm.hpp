@@ -12,8 +12,12 @@
 //   - accepted: radius /= max(1/3, 1 - (2 rho - 1)^3); rejected: radius /= nu, nu *= 2
 //   - stop on parameter / function / gradient tolerance, max iterations, min radius
 //   - additive update of the angle-axis vector (no manifold is set anywhere in the reference)
-// One device sweep per LM iteration: the candidate point is evaluated with its Jacobian, so an
+// One device sweep per LM iteration: the candidate point is evaluated with its Jacobian terms, so an
 // accepted step needs no second sweep (and a multi-GPU run needs one all-reduce per iteration).
+//
+// The solver is a resumable state machine (LmSolver): it names the point it wants evaluated next
+// (query_rot / query_tran) and is fed the normal equations there.  A single problem is a loop around it
+// (lm_solve); the batched per-pair solve advances many solvers in lock-step off one device launch.
 //
 // Build extension (SBA_TRAN_SPHERE): the translation moves in the 2-dim tangent plane of the
 // sphere |tran| = const (5-DoF R|t); Ceres users would get this with a local parameterization.
@@ -111,8 +115,7 @@ inline void tangent_basis(const double t[3], double B[6]) {
   const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
   double u[3] = {1, 0, 0};
   if (n > 0) { u[0] = t[0] / n; u[1] = t[1] / n; u[2] = t[2] / n; }
-  // pick the coordinate axis least aligned with u
-  int k = 0;
+  int k = 0;   // the coordinate axis least aligned with u
   if (std::fabs(u[1]) < std::fabs(u[k])) k = 1;
   if (std::fabs(u[2]) < std::fabs(u[k])) k = 2;
   double a[3] = {0, 0, 0};
@@ -196,132 +199,188 @@ struct Param {
 
 }  // namespace detail
 
+class LmSolver {
+ public:
+  // After start() and after every feed(): either done() or (query_rot, query_tran) is the point to evaluate next.
+  void start(int mode, const double rot0[3], const double tran0[3], const sba_lm_options& opt) {
+    mode_ = mode;
+    o_ = opt;
+    for (int a = 0; a < 3; ++a) { rot_[a] = qrot_[a] = rot0[a]; tran_[a] = qtran_[a] = tran0[a]; }
+    std::memset(&sum_, 0, sizeof(sum_));
+    sum_.termination = SBA_TERM_FAILURE;
+    phase_ = kInitial;
+    done_ = false;
+    rc_ = SBA_OK;
+    radius_ = o_.initial_trust_region_radius;
+    decrease_ = 2.0;
+    reuse_diagonal_ = false;
+    invalid_steps_ = 0;
+    iter_ = 0;
+    gmax_ = 0.0;
+    t_start_ = std::chrono::steady_clock::now();
+  }
+  bool done() const { return done_; }
+  int status() const { return rc_; }                 // SBA_OK or SBA_ERR_NUMERIC
+  const double* query_rot() const { return qrot_; }
+  const double* query_tran() const { return qtran_; }
+  const double* rot() const { return rot_; }         // current accepted point (the result once done)
+  const double* tran() const { return tran_; }
+  const sba_lm_summary& summary() const { return sum_; }
+
+  // The evaluation at the query point failed on the device side.
+  void fail() { finish(SBA_TERM_FAILURE, SBA_ERR_NUMERIC); }
+
+  // Normal equations at (query_rot, query_tran).
+  void feed(const sba_normal_eq& ne) {
+    using namespace detail;
+    if (done_) return;
+    sum_.num_evaluations++;
+    if (phase_ == kInitial) {
+      cur_ = ne;
+      if (!std::isfinite(cur_.cost)) { finish(SBA_TERM_FAILURE, SBA_ERR_NUMERIC); return; }
+      sum_.initial_cost = cur_.cost;
+      par_.build(mode_, o_.tran_param, tran_);
+      par_.project(cur_, Hf_, gf_);
+      for (int i = 0; i < par_.m; ++i)
+        scale_[i] = o_.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(std::max(Hf_[i * par_.m + i], 0.0))) : 1.0;
+      gmax_ = gmax_of(gf_);
+      if (o_.verbose)
+        std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n"
+                    "%4d % .6e    0.00e+00    %.2e   0.00e+00   0.00e+00  %.2e\n", 0, cur_.cost, gmax_, radius_);
+      if (gmax_ <= o_.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, SBA_OK); return; }
+      phase_ = kCandidate;
+      next_candidate();
+      return;
+    }
+    // phase_ == kCandidate: ne is the evaluation at the candidate
+    const bool rot_free = mode_ != SBA_MODE_TRAN, tran_free = mode_ != SBA_MODE_ROT;
+    double step2 = 0, x2 = 0;
+    for (int a = 0; a < 3; ++a) {
+      if (rot_free) { step2 += (qrot_[a] - rot_[a]) * (qrot_[a] - rot_[a]); x2 += rot_[a] * rot_[a]; }
+      if (tran_free) { step2 += (qtran_[a] - tran_[a]) * (qtran_[a] - tran_[a]); x2 += tran_[a] * tran_[a]; }
+    }
+    const double step_norm = std::sqrt(step2), x_norm = std::sqrt(x2);
+    const double cost_change = cur_.cost - ne.cost;
+    const double rho = std::isfinite(ne.cost) ? cost_change / model_change_ : -1.0;
+    if (o_.verbose)
+      std::printf("%4d % .6e   % .2e    %.2e   %.2e  % .2e  %.2e\n", iter_, ne.cost, cost_change, gmax_, step_norm,
+                  rho, radius_);
+    if (step_norm <= o_.parameter_tolerance * (x_norm + o_.parameter_tolerance)) {
+      finish(SBA_TERM_CONVERGENCE_PARAMETER, SBA_OK);
+      return;
+    }
+    if (std::isfinite(ne.cost) && std::fabs(cost_change) <= o_.function_tolerance * cur_.cost) {
+      finish(SBA_TERM_CONVERGENCE_FUNCTION, SBA_OK);
+      return;
+    }
+    if (rho > o_.min_relative_decrease) {
+      for (int a = 0; a < 3; ++a) { rot_[a] = qrot_[a]; tran_[a] = qtran_[a]; }
+      cur_ = ne;
+      sum_.num_successful_steps++;
+      par_.build(mode_, o_.tran_param, tran_);
+      par_.project(cur_, Hf_, gf_);
+      gmax_ = gmax_of(gf_);
+      const double t3 = 2.0 * rho - 1.0;
+      radius_ = std::min(o_.max_trust_region_radius, radius_ / std::max(1.0 / 3.0, 1.0 - t3 * t3 * t3));
+      decrease_ = 2.0;
+      reuse_diagonal_ = false;
+      if (gmax_ <= o_.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, SBA_OK); return; }
+    } else {
+      radius_ /= decrease_; decrease_ *= 2.0; reuse_diagonal_ = true;
+    }
+    next_candidate();
+  }
+
+ private:
+  enum Phase { kInitial, kCandidate };
+
+  double gmax_of(const double* g) const {
+    double v = 0;
+    for (int i = 0; i < par_.m; ++i) v = std::max(v, std::fabs(g[i]));
+    return v;
+  }
+  void finish(int term, int rc) {
+    sum_.termination = term;
+    sum_.final_cost = cur_.cost;
+    sum_.final_gradient_max_norm = gmax_;
+    sum_.final_radius = radius_;
+    sum_.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start_).count();
+    for (int a = 0; a < 3; ++a) { qrot_[a] = rot_[a]; qtran_[a] = tran_[a]; }
+    rc_ = rc;
+    done_ = true;
+  }
+  // Trust-region step(s) from the current point until one is valid: sets the query point, or terminates.
+  void next_candidate() {
+    using namespace detail;
+    const int m = par_.m;
+    for (;;) {
+      ++iter_;
+      if (iter_ > o_.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, SBA_OK); return; }
+      if (radius_ < o_.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, SBA_OK); return; }
+      sum_.num_iterations = iter_;
+      double Hs[36], gs[6], A[36], rhs[6], y[6];
+      for (int i = 0; i < m; ++i) {
+        gs[i] = scale_[i] * gf_[i];
+        for (int j = 0; j < m; ++j) Hs[i * m + j] = scale_[i] * Hf_[i * m + j] * scale_[j];
+      }
+      if (!reuse_diagonal_)
+        for (int i = 0; i < m; ++i)
+          diag_[i] = std::min(std::max(Hs[i * m + i], o_.min_lm_diagonal), o_.max_lm_diagonal);
+      std::memcpy(A, Hs, sizeof(double) * m * m);
+      for (int i = 0; i < m; ++i) { A[i * m + i] += diag_[i] / radius_; rhs[i] = -gs[i]; }
+      bool valid = cholesky_solve(m, A, rhs, y);
+      if (valid) {
+        // -(J y)^T (f + J y / 2) = -g^T y - y^T H y / 2
+        double gy = 0, yHy = 0;
+        for (int i = 0; i < m; ++i) {
+          gy += gs[i] * y[i];
+          double s = 0;
+          for (int j = 0; j < m; ++j) s += Hs[i * m + j] * y[j];
+          yHy += y[i] * s;
+        }
+        model_change_ = -gy - 0.5 * yHy;
+        valid = model_change_ > 0.0;
+      }
+      if (!valid) {
+        if (++invalid_steps_ >= 5) { finish(SBA_TERM_FAILURE, SBA_ERR_NUMERIC); return; }
+        radius_ /= decrease_; decrease_ *= 2.0; reuse_diagonal_ = true;
+        continue;
+      }
+      invalid_steps_ = 0;
+      double delta[6];
+      for (int i = 0; i < m; ++i) delta[i] = scale_[i] * y[i];
+      par_.plus(rot_, tran_, delta, qrot_, qtran_);
+      return;
+    }
+  }
+
+  int mode_ = 0;
+  sba_lm_options o_{};
+  sba_lm_summary sum_{};
+  detail::Param par_;
+  sba_normal_eq cur_{};
+  double rot_[3] = {0, 0, 0}, tran_[3] = {0, 0, 0}, qrot_[3] = {0, 0, 0}, qtran_[3] = {0, 0, 0};
+  double Hf_[36] = {0}, gf_[6] = {0}, scale_[6] = {0}, diag_[6] = {0};
+  double radius_ = 0, decrease_ = 2, model_change_ = 0, gmax_ = 0;
+  bool reuse_diagonal_ = false, done_ = false;
+  int invalid_steps_ = 0, iter_ = 0, rc_ = SBA_OK;
+  Phase phase_ = kInitial;
+  std::chrono::steady_clock::time_point t_start_;
+};
+
 // Evaluator: bool(const double rot[3], const double tran[3], sba_normal_eq* out)
 template <typename Evaluator>
 int lm_solve(int mode, double rot[3], double tran[3], const sba_lm_options& o, Evaluator&& evaluate,
              sba_lm_summary* sum) {
-  using namespace detail;
-  const auto t_start = std::chrono::steady_clock::now();
-  std::memset(sum, 0, sizeof(*sum));
-  sum->termination = SBA_TERM_FAILURE;
-  auto finish = [&](int term, double cost, double gmax, double radius) {
-    sum->termination = term;
-    sum->final_cost = cost;
-    sum->final_gradient_max_norm = gmax;
-    sum->final_radius = radius;
-    sum->seconds_total =
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  };
-  const bool rot_free = mode != SBA_MODE_TRAN, tran_free = mode != SBA_MODE_ROT;
-
-  sba_normal_eq cur;
-  if (!evaluate(rot, tran, &cur)) { finish(SBA_TERM_FAILURE, 0, 0, 0); return SBA_ERR_NUMERIC; }
-  sum->num_evaluations = 1;
-  if (!std::isfinite(cur.cost)) { finish(SBA_TERM_FAILURE, cur.cost, 0, 0); return SBA_ERR_NUMERIC; }
-  sum->initial_cost = cur.cost;
-
-  Param par;
-  par.build(mode, o.tran_param, tran);
-  const int m = par.m;
-  double Hf[36], gf[6], scale[6];
-  par.project(cur, Hf, gf);
-  for (int i = 0; i < m; ++i)
-    scale[i] = o.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(std::max(Hf[i * m + i], 0.0))) : 1.0;
-  auto gmax_of = [&](const double* g) {
-    double v = 0;
-    for (int i = 0; i < m; ++i) v = std::max(v, std::fabs(g[i]));
-    return v;
-  };
-  double gmax = gmax_of(gf);
-  double radius = o.initial_trust_region_radius, decrease = 2.0;
-  bool reuse_diagonal = false;
-  double diag[6] = {0};
-  if (o.verbose)
-    std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n"
-                "%4d % .6e    0.00e+00    %.2e   0.00e+00   0.00e+00  %.2e\n", 0, cur.cost, gmax, radius);
-  if (gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cur.cost, gmax, radius); return SBA_OK; }
-
-  int invalid_steps = 0;
-  for (int iter = 1;; ++iter) {
-    if (iter > o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cur.cost, gmax, radius); return SBA_OK; }
-    if (radius < o.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, cur.cost, gmax, radius); return SBA_OK; }
-    sum->num_iterations = iter;
-
-    // scaled system
-    double Hs[36], gs[6], A[36], rhs[6], y[6];
-    for (int i = 0; i < m; ++i) {
-      gs[i] = scale[i] * gf[i];
-      for (int j = 0; j < m; ++j) Hs[i * m + j] = scale[i] * Hf[i * m + j] * scale[j];
-    }
-    if (!reuse_diagonal)
-      for (int i = 0; i < m; ++i)
-        diag[i] = std::min(std::max(Hs[i * m + i], o.min_lm_diagonal), o.max_lm_diagonal);
-    std::memcpy(A, Hs, sizeof(double) * m * m);
-    for (int i = 0; i < m; ++i) { A[i * m + i] += diag[i] / radius; rhs[i] = -gs[i]; }
-    bool valid = cholesky_solve(m, A, rhs, y);
-    double model_change = 0.0;
-    if (valid) {
-      // -(J y)^T (f + J y / 2) = -g^T y - y^T H y / 2
-      double gy = 0, yHy = 0;
-      for (int i = 0; i < m; ++i) {
-        gy += gs[i] * y[i];
-        double s = 0;
-        for (int j = 0; j < m; ++j) s += Hs[i * m + j] * y[j];
-        yHy += y[i] * s;
-      }
-      model_change = -gy - 0.5 * yHy;
-      valid = model_change > 0.0;
-    }
-    if (!valid) {
-      if (++invalid_steps >= 5) { finish(SBA_TERM_FAILURE, cur.cost, gmax, radius); return SBA_ERR_NUMERIC; }
-      radius /= decrease; decrease *= 2.0; reuse_diagonal = true;
-      continue;
-    }
-    invalid_steps = 0;
-    double delta[6];
-    for (int i = 0; i < m; ++i) delta[i] = scale[i] * y[i];
-
-    double rot_c[3], tran_c[3];
-    par.plus(rot, tran, delta, rot_c, tran_c);
-    sba_normal_eq cand;
-    if (!evaluate(rot_c, tran_c, &cand)) { finish(SBA_TERM_FAILURE, cur.cost, gmax, radius); return SBA_ERR_NUMERIC; }
-    sum->num_evaluations++;
-
-    double step2 = 0, x2 = 0;
-    for (int a = 0; a < 3; ++a) {
-      if (rot_free) { step2 += (rot_c[a] - rot[a]) * (rot_c[a] - rot[a]); x2 += rot[a] * rot[a]; }
-      if (tran_free) { step2 += (tran_c[a] - tran[a]) * (tran_c[a] - tran[a]); x2 += tran[a] * tran[a]; }
-    }
-    const double step_norm = std::sqrt(step2), x_norm = std::sqrt(x2);
-    const double cost_change = cur.cost - cand.cost;
-    const double rho = std::isfinite(cand.cost) ? cost_change / model_change : -1.0;
-    if (o.verbose)
-      std::printf("%4d % .6e   % .2e    %.2e   %.2e  % .2e  %.2e\n", iter, cand.cost, cost_change,
-                  gmax, step_norm, rho, radius);
-    if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
-      finish(SBA_TERM_CONVERGENCE_PARAMETER, cur.cost, gmax, radius);
-      return SBA_OK;
-    }
-    if (std::isfinite(cand.cost) && std::fabs(cost_change) <= o.function_tolerance * cur.cost) {
-      finish(SBA_TERM_CONVERGENCE_FUNCTION, cur.cost, gmax, radius);
-      return SBA_OK;
-    }
-    if (rho > o.min_relative_decrease) {
-      for (int a = 0; a < 3; ++a) { rot[a] = rot_c[a]; tran[a] = tran_c[a]; }
-      cur = cand;
-      sum->num_successful_steps++;
-      par.build(mode, o.tran_param, tran);
-      par.project(cur, Hf, gf);
-      gmax = gmax_of(gf);
-      const double t3 = 2.0 * rho - 1.0;
-      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t3 * t3 * t3));
-      decrease = 2.0;
-      reuse_diagonal = false;
-      if (gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cur.cost, gmax, radius); return SBA_OK; }
-    } else {
-      radius /= decrease; decrease *= 2.0; reuse_diagonal = true;
-    }
+  LmSolver s;
+  s.start(mode, rot, tran, o);
+  while (!s.done()) {
+    sba_normal_eq ne;
+    if (evaluate(s.query_rot(), s.query_tran(), &ne)) s.feed(ne); else s.fail();
   }
+  for (int a = 0; a < 3; ++a) { rot[a] = s.rot()[a]; tran[a] = s.tran()[a]; }
+  *sum = s.summary();
+  return s.status();
 }
 
 }  // namespace sba

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sba_device.hpp"
+#include "sba_internal.hpp"
 #include "sba_lm.hpp"
 #include "sba_rotation.hpp"
 
@@ -33,6 +34,34 @@ int fail(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
+}  // namespace
+
+namespace sba {
+int set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+void make_sweep_params(size_t n, int depth_mode, const double rot[3], const double tran[3], double d1, double d2,
+                       double huber_delta, SweepParams* prm) {
+  double R[9], G[27];
+  rotation_and_derivatives(rot, R, G);
+  const double scale = depth_mode == SBA_DEPTH_UNIFORM ? -d1 : -1.0;
+  for (int i = 0; i < 9; ++i) prm->Rn[i] = scale * R[i];
+  for (int i = 0; i < 27; ++i) prm->Gn[i] = scale * G[i];
+  for (int i = 0; i < 3; ++i) prm->t[i] = tran[i];
+  prm->d2 = d2;
+  prm->delta = huber_delta > 0.0 ? huber_delta : 0.0;
+  prm->delta2 = prm->delta * prm->delta;
+  prm->n = n;
+}
+}  // namespace sba
+
+namespace {
 
 #define SBA_HIP_TRY(expr)                                                                   \
   do {                                                                                      \
@@ -203,16 +232,7 @@ int check_args(const sba_problem* p, int mode, int depth_mode, const double* rot
 
 void make_params(const sba_problem* p, int depth_mode, const double rot[3], const double tran[3],
                  double d1, double d2, double huber_delta, sba::SweepParams* prm) {
-  double R[9], G[27];
-  sba::rotation_and_derivatives(rot, R, G);
-  const double scale = depth_mode == SBA_DEPTH_UNIFORM ? -d1 : -1.0;
-  for (int i = 0; i < 9; ++i) prm->Rn[i] = scale * R[i];
-  for (int i = 0; i < 27; ++i) prm->Gn[i] = scale * G[i];
-  for (int i = 0; i < 3; ++i) prm->t[i] = tran[i];
-  prm->d2 = d2;
-  prm->delta = huber_delta > 0.0 ? huber_delta : 0.0;
-  prm->delta2 = prm->delta * prm->delta;
-  prm->n = p->n;
+  sba::make_sweep_params(p->n, depth_mode, rot, tran, d1, d2, huber_delta, prm);
 }
 
 void make_frame(sba_problem* p, int mode, const double rot[3]) {

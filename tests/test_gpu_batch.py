@@ -1,0 +1,119 @@
+"""GPU (-m gpu): batched per-pair sweeps and LM (BASELINE config C5 shape, scaled down) against per-pair oracle /
+single-problem results; ragged and empty pairs; both kernels; equi2cube on a batch of frames."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import REL_TOL_F64, RT_TOL_F64, pack_from_eval
+from spherical_bundle_adjuster_amd import _cabi as cabi
+from spherical_bundle_adjuster_amd import api, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_pairs(sizes, seed0=900, rt=True):
+    cs = [(synthetic.full_rt if rt else synthetic.rotation_only)(n, seed=seed0 + i) for i, n in enumerate(sizes)]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    x1 = np.concatenate([c.x1 for c in cs]) if sum(sizes) else np.zeros((0, 3))
+    x2 = np.concatenate([c.x2 for c in cs]) if sum(sizes) else np.zeros((0, 3))
+    d12 = np.concatenate([c.d12 for c in cs]) if rt and sum(sizes) else (np.zeros((0, 2)) if rt else None)
+    return cs, off, x1, x2, d12
+
+
+@pytest.mark.parametrize("kind", [api.KERNEL_FACTORED, api.KERNEL_EXPLICIT], ids=["factored", "explicit"])
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+def test_batch_eval_matches_oracle(oracle, kind, store):
+    sizes = [1, 0, 63, 64, 65, 1000, 2, 513, 3001, 7]
+    cs, off, x1, x2, d12 = _make_pairs(sizes)
+    rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
+    with api.Batch(0) as b:
+        b.set_kernel(kind)
+        b.upload(x1, x2, off, d12, store=store)
+        for mode in (api.MODE_ROT, api.MODE_TRAN, api.MODE_RT):
+            for dm in (api.DEPTH_PER_MATCH, api.DEPTH_UNIFORM):
+                d1 = np.linspace(0.8, 1.7, len(sizes)); d2 = np.linspace(1.3, 0.6, len(sizes))
+                packs = b.eval(mode, rot, tran, d1, d2, 1.0, dm)
+                for g, c in enumerate(cs):
+                    a1, a2 = ((c.x1, c.x2) if store == api.STORE_F64 else
+                              (c.x1.astype(np.float32).astype(np.float64), c.x2.astype(np.float32).astype(np.float64)))
+                    ref = pack_from_eval(mode, oracle.evaluate(mode, a1, a2, c.rot_init, c.tran_init, d1[g], d2[g], 1.0,
+                                                               c.d12 if dm == api.DEPTH_PER_MATCH else None))
+                    scale = max(np.abs(ref).max(), 1e-300)
+                    assert np.abs(packs[g] - ref).max() <= REL_TOL_F64 * scale, (mode, dm, g, sizes[g])
+
+
+def test_batch_solve_matches_single_problem_solves(oracle):
+    sizes = [4000, 0, 2500, 3333, 1, 5000]
+    cs, off, x1, x2, d12 = _make_pairs(sizes)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, d12)
+        for mode, tp in ((api.MODE_RT, api.TRAN_SPHERE), (api.MODE_ROT, api.TRAN_FREE)):
+            opt = api.default_lm_options(tran_param=tp)
+            rot, tran, sums, status = b.solve(mode, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, options=opt)
+            assert (status == 0).all()
+            for g, c in enumerate(cs):
+                if sizes[g] == 0:
+                    assert np.array_equal(rot[g], rot0[g]) and sums[g].num_evaluations == 1
+                    continue
+                ro, to, so, rc = oracle.lm_solve(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12,
+                                                 options=oracle.default_options(tran_param=tp))
+                assert rc == 0
+                assert (sums[g].num_iterations, sums[g].num_successful_steps) == (so.num_iterations, so.num_successful_steps), g
+                assert np.abs(rot[g] - ro).max() <= RT_TOL_F64 and np.abs(tran[g] - to).max() <= RT_TOL_F64
+                with api.Problem(0) as p:       # and the single-problem API gives the same answer
+                    p.upload(c.x1, c.x2, c.d12)
+                    r1, t1, s1 = p.solve(mode, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, options=opt)
+                assert np.abs(rot[g] - r1).max() <= 1e-12 and np.abs(tran[g] - t1).max() <= 1e-12
+
+
+def test_batch_config_c5_shape_properties():
+    """64 pairs x 50k matches (config C5 is 256 x 50k; same per-pair size, a quarter of the pairs to keep host-side
+    data generation short): every pair converges to its own geometry, repeated launches are bit-identical."""
+    B, n = 64, 50_000
+    cs, off, x1, x2, d12 = _make_pairs([n] * B, seed0=5000)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, d12)
+        p1 = b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH)
+        assert np.array_equal(p1, b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH))
+        rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
+                                          options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+        assert (status == 0).all() and all(s.termination.startswith("CONVERGENCE") for s in sums)
+        err = np.array([np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)])
+        assert err.max() < 5e-3
+        assert np.allclose(np.linalg.norm(tran, axis=1), 1.0, atol=1e-12)
+
+
+def test_batch_errors_and_empty():
+    with api.Batch(0) as b:
+        with pytest.raises(api.SbaError):
+            b.eval(api.MODE_ROT, np.zeros((0, 3)), np.zeros((0, 3)))             # nothing uploaded
+        b.upload(np.zeros((0, 3)), np.zeros((0, 3)), np.array([0], dtype=np.uint64))
+        assert b.eval(api.MODE_ROT, np.zeros((0, 3)), np.zeros((0, 3))).shape == (0, 24)
+        c = synthetic.rotation_only(100, seed=1)
+        b.upload(c.x1, c.x2, np.array([0, 40, 100], dtype=np.uint64))
+        with pytest.raises(api.SbaError):
+            b.eval(api.MODE_ROT, np.zeros((2, 3)), np.zeros((2, 3)), depth_mode=api.DEPTH_PER_MATCH)
+        with pytest.raises(ValueError):
+            b.upload(c.x1, c.x2, np.array([0, 400], dtype=np.uint64))
+
+
+def test_equi2cube_batched_device(oracle):
+    """Batched, device-resident remap (config C5: "equi2cube remap on GPU") through torch-owned memory."""
+    torch = pytest.importorskip("torch")
+    lib = cabi.load_library()
+    B, H, W, S = 3, 240, 480, 60
+    rng = np.random.default_rng(9)
+    ims = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    src = torch.from_numpy(ims).cuda()
+    dst = torch.zeros((B, S, 6 * S, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    cabi.check(lib, lib.sba_equi2cube_device(0, C.c_void_p(stream), C.c_void_p(src.data_ptr()), H, W, S, B,
+                                             C.c_void_p(dst.data_ptr())))
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy()
+    for k in range(B):
+        ref, _ = oracle.equi2cube(ims[k], S)
+        assert np.array_equal(out[k], ref)
