@@ -59,6 +59,9 @@ hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& 
                         const SweepOut& out, int grid, hipStream_t stream);
 hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream);
+// pack_dev[24] -> mapped pinned host memory, then `seq` at pack_host[24] (64-bit) for the host to poll.
+hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,
+                          hipStream_t stream);
 
 // Batched problems (config C5): pair g owns vectors [first_vec, first_vec + ceil(n/PPT)) of the shared planes and
 // params[g] (its own R|t; params[g].n = 0 skips the pair).  bpp blocks per pair; partials [num_pairs*bpp][kRow];

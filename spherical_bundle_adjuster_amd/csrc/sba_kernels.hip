@@ -31,7 +31,7 @@
 #endif
 #ifndef SBA_NT_LOADS
 #define SBA_NT_LOADS 1     // the once-read coordinate stream is loaded non-temporally (global_load ... nt):
-                           // measured +10-12 % sweep bandwidth on MI355X (profiles/r01_variants.md)
+                           // measured +10-12 % sweep bandwidth on MI355X (profiles/r01_tune_variants_10M.log)
 #endif
 
 namespace sba {
@@ -540,6 +540,18 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict
   }
 }
 
+// After a collective (the all-reduced pack sits in device memory): one wave copies it into mapped pinned host
+// memory and releases the sequence number the host polls -- no blit kernel, no stream synchronisation.
+__global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ pack_dev,
+                                                     double* __restrict__ pack_host, unsigned long long seq) {
+  if (threadIdx.x < 24) pack_host[threadIdx.x] = pack_dev[threadIdx.x];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- layout conversion at upload time (once per problem, not per LM iteration) ---------------
 template <typename ST>
 __global__ void aos_to_planes_kernel(const double* __restrict__ aos, size_t n, size_t first,
@@ -622,34 +634,45 @@ __device__ __forceinline__ int erp_source_index(int face, int i, int j, int S, i
 template <int PIX>
 __global__ __launch_bounds__(256) void equi2cube_kernel(const uint8_t* __restrict__ erp, int im_h,
                                                         int im_w, int S, uint8_t* __restrict__ out,
-                                                        size_t erp_stride, size_t out_stride) {
+                                                        size_t erp_stride, size_t out_stride, int batch,
+                                                        int frames_per_block) {
   const int groups_per_row = (6 * S) / PIX;
   const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= static_cast<size_t>(groups_per_row) * S) return;
-  const uint8_t* src = erp + static_cast<size_t>(blockIdx.y) * erp_stride;
-  uint8_t* dst = out + static_cast<size_t>(blockIdx.y) * out_stride;
   const int i = static_cast<int>(g / groups_per_row);
   const int c0 = static_cast<int>(g % groups_per_row) * PIX;   // strip column of the first pixel
-  uint8_t px[3 * PIX];
+  // The mapping depends only on (S, H, W): the f64 sqrt/acos/atan2 work is done once per output pixel and
+  // reused for every frame of this block's slice of the batch; per frame only the gather and the store remain.
+  size_t si[PIX];
 #pragma unroll
   for (int k = 0; k < PIX; ++k) {
     const int c = c0 + k;
     const int face = c / S, j = c - face * S;
-    const size_t si = static_cast<size_t>(erp_source_index(face, i, j, S, im_h, im_w)) * 3;
-    px[3 * k + 0] = src[si + 0];
-    px[3 * k + 1] = src[si + 1];
-    px[3 * k + 2] = src[si + 2];
+    si[k] = static_cast<size_t>(erp_source_index(face, i, j, S, im_h, im_w)) * 3;
   }
   const size_t o = (static_cast<size_t>(i) * 6 * S + c0) * 3;
-  if (PIX == 4) {
-    uint32_t* o32 = reinterpret_cast<uint32_t*>(dst + o);   // 12-byte group, 4-byte aligned
+  const int f0 = blockIdx.y * frames_per_block;
+  const int f1 = min(batch, f0 + frames_per_block);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* src = erp + static_cast<size_t>(f) * erp_stride;
+    uint8_t* dst = out + static_cast<size_t>(f) * out_stride;
+    uint8_t px[3 * PIX];
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
-      o32[w] = static_cast<uint32_t>(px[4 * w]) | (static_cast<uint32_t>(px[4 * w + 1]) << 8) |
-               (static_cast<uint32_t>(px[4 * w + 2]) << 16) | (static_cast<uint32_t>(px[4 * w + 3]) << 24);
-  } else {
+    for (int k = 0; k < PIX; ++k) {
+      px[3 * k + 0] = src[si[k] + 0];
+      px[3 * k + 1] = src[si[k] + 1];
+      px[3 * k + 2] = src[si[k] + 2];
+    }
+    if (PIX == 4) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(dst + o);   // 12-byte group, 4-byte aligned
 #pragma unroll
-    for (int b = 0; b < 3 * PIX; ++b) dst[o + b] = px[b];
+      for (int w = 0; w < 3; ++w)
+        o32[w] = static_cast<uint32_t>(px[4 * w]) | (static_cast<uint32_t>(px[4 * w + 1]) << 8) |
+                 (static_cast<uint32_t>(px[4 * w + 2]) << 16) | (static_cast<uint32_t>(px[4 * w + 3]) << 24);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 3 * PIX; ++b) dst[o + b] = px[b];
+    }
   }
 }
 
@@ -749,6 +772,12 @@ hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& 
   return hipGetLastError();
 }
 
+hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, stream, pack_dev, pack_host_dev, seq);
+  return hipGetLastError();
+}
+
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream) {
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out);
   return hipGetLastError();
@@ -797,15 +826,19 @@ hipError_t launch_equi2cube(const uint8_t* erp, int im_h, int im_w, int cube, in
   if (cube <= 0 || batch <= 0) return hipSuccess;
   const size_t erp_stride = static_cast<size_t>(im_h) * im_w * 3;
   const size_t out_stride = static_cast<size_t>(cube) * 6 * cube * 3;
-  if ((6 * cube) % 4 == 0 && cube % 4 == 0) {
-    const size_t groups = static_cast<size_t>(6 * cube / 4) * cube;
-    hipLaunchKernelGGL((equi2cube_kernel<4>), dim3(static_cast<unsigned>((groups + 255) / 256), batch),
-                       dim3(256), 0, stream, erp, im_h, im_w, cube, out, erp_stride, out_stride);
-  } else {
-    const size_t groups = static_cast<size_t>(6 * cube) * cube;
-    hipLaunchKernelGGL((equi2cube_kernel<1>), dim3(static_cast<unsigned>((groups + 255) / 256), batch),
-                       dim3(256), 0, stream, erp, im_h, im_w, cube, out, erp_stride, out_stride);
-  }
+  const bool wide = (6 * cube) % 4 == 0 && cube % 4 == 0;
+  const size_t groups = wide ? static_cast<size_t>(6 * cube / 4) * cube : static_cast<size_t>(6 * cube) * cube;
+  const unsigned gx = static_cast<unsigned>((groups + 255) / 256);
+  // frames per block: amortise the index computation over the batch, but keep >= ~2048 blocks in flight
+  int fpb = 1;
+  while (fpb < 16 && fpb * 2 <= batch && static_cast<size_t>(gx) * ((batch + 2 * fpb - 1) / (2 * fpb)) >= 2048) fpb *= 2;
+  const unsigned gy = static_cast<unsigned>((batch + fpb - 1) / fpb);
+  if (wide)
+    hipLaunchKernelGGL((equi2cube_kernel<4>), dim3(gx, gy), dim3(256), 0, stream, erp, im_h, im_w, cube, out,
+                       erp_stride, out_stride, batch, fpb);
+  else
+    hipLaunchKernelGGL((equi2cube_kernel<1>), dim3(gx, gy), dim3(256), 0, stream, erp, im_h, im_w, cube, out,
+                       erp_stride, out_stride, batch, fpb);
   return hipGetLastError();
 }
 

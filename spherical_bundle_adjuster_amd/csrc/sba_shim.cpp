@@ -277,6 +277,11 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
     const int rc = p->hook(p->pack_dev, SBA_PACK_SIZE, p->stream, p->hook_user);
     if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
   }
+  if (collective && p->fused) {
+    // the all-reduced pack is published by a one-wave kernel (host polls), like the single-GPU sweep does itself
+    SBA_HIP_TRY(sba::launch_publish(p->pack_dev, p->pack_host_dev, ++p->seq, p->stream));
+    p->published = true;
+  }
   return SBA_OK;
 }
 
