@@ -187,6 +187,8 @@ int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const vo
                               const void* d12_dev, size_t n, int store);
 
 int sba_problem_size(const sba_problem* p, size_t* n);
+/* (Re)upload only the per-match depths d12 (double[2n], init_d layout) of the resident correspondences.    */
+int sba_problem_set_depths(sba_problem* p, const double* d12);
 /* Select the sweep kernel (SBA_KERNEL_*); also settable with the environment variable
  * SBA_KERNEL=explicit at sba_problem_create time.                                                 */
 int sba_problem_set_kernel(sba_problem* p, int kind);
@@ -252,6 +254,23 @@ int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
 /* Device address of the 24-double result pack the hook / RCCL operates on (a sum over
  * correspondences in either kernel's layout, so summing it across shards is exact).            */
 int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);
+
+/* ---- 8-point initial guess (eight_point_estimation / initial_guess, spherical_bundle_adjuster.cpp:47-181) ---- */
+/* Device part: one pass over the uploaded correspondences accumulating A^T A of the rows kron(left_i, right_i)
+ * (.cpp:53-68) for 64 interleaved groups, group(i) = (i / 4) % 64.  groups: double[64][45] (upper triangle,
+ * row-major a <= b).                                                                                         */
+int sba_problem_epipolar_moments(sba_problem* p, double* groups);
+/* Host part (no device needed): `trials` trials (80 in the reference, .cpp:130), each on a random
+ * `subset_fraction` (0.25, .cpp:133) of the groups: null vector of A (smallest eigenvector of A^T A), rank-2
+ * projection, decomposeEssentialMat, Euler angles, validity (< 1.57), consensus pick by 20-80 % trimmed mean
+ * distance.  Outputs R_vec_out (Euler angles) and T_vec_out of the reference; the reference then starts the BA
+ * from init_rot = -R_vec_out, init_tran = T_vec_out (.cpp:330-331).                                          */
+int sba_initial_guess_from_moments(const double* groups, int trials, double subset_fraction,
+                                   unsigned long long seed, double rot_euler[3], double tran[3],
+                                   int* num_candidates);
+/* Both parts.                                                                                                */
+int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction, unsigned long long seed,
+                              double rot_euler[3], double tran[3], int* num_candidates);
 
 /* ---- batched per-pair solve (BASELINE config C5: many ERP pairs, each its own two-view problem) ------- */
 /* The reference handles one image pair per process run (main/main.cpp:6-34); a batch holds `num_pairs`

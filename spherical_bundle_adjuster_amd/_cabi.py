@@ -86,6 +86,7 @@ SIGNATURES = {
     "sba_problem_upload_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
     "sba_problem_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "sba_problem_set_kernel": (C.c_int, [_vp, C.c_int]),
+    "sba_problem_set_depths": (C.c_int, [_vp, _vp]),
     "sba_problem_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                    C.c_double, C.POINTER(NormalEq)]),
     "sba_problem_eval_pack": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
@@ -99,6 +100,10 @@ SIGNATURES = {
                                     C.POINTER(LmOptions), C.POINTER(LmSummary)]),
     "sba_problem_solve_depths": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_double, C.POINTER(LmOptions), _vp,
                                            C.POINTER(LmSummary)]),
+    "sba_problem_epipolar_moments": (C.c_int, [_vp, _dp]),
+    "sba_initial_guess_from_moments": (C.c_int, [_dp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp,
+                                                 C.POINTER(C.c_int)]),
+    "sba_problem_initial_guess": (C.c_int, [_vp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp, C.POINTER(C.c_int)]),
     "sba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sba_problem_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "sba_problem_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),

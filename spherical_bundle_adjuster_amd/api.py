@@ -136,6 +136,13 @@ class Problem:
         cabi.check(self._lib, self._lib.sba_problem_upload_device(
             self._h, C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_void_p(d12_ptr or 0), n, store))
 
+    def set_depths(self, d12) -> None:
+        """(Re)upload only the per-match depths (n, 2) of the resident correspondences."""
+        d = _f64(d12).reshape(-1, 2)
+        if d.shape[0] != self.size:
+            raise ValueError("d12 length differs from the uploaded correspondences")
+        cabi.check(self._lib, self._lib.sba_problem_set_depths(self._h, d.ctypes.data_as(C.c_void_p)))
+
     def set_kernel(self, kind: int) -> None:
         """KERNEL_FACTORED (default) or KERNEL_EXPLICIT."""
         cabi.check(self._lib, self._lib.sba_problem_set_kernel(self._h, kind))
@@ -203,6 +210,20 @@ class Problem:
                                                                  C.byref(opt), out.ctypes.data_as(C.c_void_p),
                                                                  C.byref(s)))
         return out, _summary(s)
+
+    # -- 8-point initial guess ----------------------------------------------------------------------
+    def epipolar_moments(self) -> np.ndarray:
+        """(64, 45): upper triangle of A^T A of the kron(left, right) rows per interleaved group (i//4) % 64."""
+        g = np.zeros((64, 45))
+        cabi.check(self._lib, self._lib.sba_problem_epipolar_moments(self._h, _dptr(g)))
+        return g
+
+    def initial_guess(self, trials: int = 80, subset_fraction: float = 0.25, seed: int = 0):
+        """Returns (euler (3,), tran (3,), number of candidates): R_vec_out / T_vec_out of the reference."""
+        e, t, n = np.zeros(3), np.zeros(3), C.c_int(0)
+        cabi.check(self._lib, self._lib.sba_problem_initial_guess(self._h, trials, subset_fraction, seed, _dptr(e),
+                                                                  _dptr(t), C.byref(n)))
+        return e, t, n.value
 
     # -- multi-GPU ------------------------------------------------------------------------------------
     def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes) -> None:
@@ -315,6 +336,16 @@ class Batch:
         cabi.check(self._lib, self._lib.sba_batch_solve(self._h, mode, depth_mode, _dptr(rot), _dptr(tran), d1p, d2p,
                                                         C.byref(opt), sums, status.ctypes.data_as(C.POINTER(C.c_int))))
         return rot, tran, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
+
+
+def initial_guess_from_moments(groups, trials: int = 80, subset_fraction: float = 0.25, seed: int = 0):
+    """Host-only part of the initial guess (no device needed)."""
+    lib = cabi.load_library()
+    g = _f64(groups, (64, 45))
+    e, t, n = np.zeros(3), np.zeros(3), C.c_int(0)
+    cabi.check(lib, lib.sba_initial_guess_from_moments(_dptr(g), trials, subset_fraction, seed, _dptr(e), _dptr(t),
+                                                       C.byref(n)))
+    return e, t, n.value
 
 
 def comm_unique_id() -> bytes:

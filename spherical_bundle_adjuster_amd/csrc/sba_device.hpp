@@ -104,6 +104,11 @@ hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, cons
                              const DepthParams& prm, double* partials, int grid, double* out8,
                              hipStream_t stream);
 
+// 8-point initial guess, device part (.cpp:53-68): A^T A of the kron(left, right) rows for 64 interleaved groups.
+// groups_dev: [64][45]; partials: [grid][45][64] scratch.
+hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double* partials, int grid,
+                                   double* groups_dev, hipStream_t stream);
+
 // pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
 hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride_bytes, double im_w,
                                       double im_h, double* out_xyz, hipStream_t stream);

@@ -1,0 +1,275 @@
+// Host side of the 8-point initial guess (reference spherical_bundle_adjuster.cpp:47-181).
+//
+// The reference runs 80 trials; each draws a random 25 % subset of the matches (random_shuffle on never-seeded
+// rand(), .hpp:182-211 -- deterministic per libc, not portable), stacks the rows kron(left_i, right_i) into an
+// m x 9 matrix A (.cpp:53-68), takes the right singular vector of the smallest singular value (.cpp:70-74),
+// projects the 3x3 E onto rank 2 (.cpp:75-80), decomposes it into R1, R2, t (cv::decomposeEssentialMat, .cpp:85),
+// converts both rotations to Euler angles (rot2euler, .cpp:25-45) and keeps those whose largest |angle| is below
+// 1.57 (.cpp:101-115); the candidate closest to the others in the 20-80 % trimmed-mean sense wins (.cpp:162-180).
+//
+// Here the O(N) part is one device pass (sba_epipolar.hip) that accumulates A^T A separately for 64 interleaved
+// groups of matches (group = (index / 4) % 64); a trial's subset is the union of a random quarter of the groups, so
+// its A^T A is a sum of 16 small matrices and the null vector of A is the eigenvector of the smallest eigenvalue of
+// A^T A.  Sampling whole groups instead of single matches is the documented deviation (the reference's own
+// sampling cannot be reproduced across C libraries anyway); everything after the null vector follows the reference
+// step by step.  All of it is tiny 9x9 / 3x3 host work.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace sba {
+namespace epi {
+
+constexpr int kGroups = 64;     // interleaved groups of matches: group(i) = (i / 4) % 64
+constexpr int kMom = 45;        // upper triangle of the 9x9 A^T A
+
+// ---- cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9) -------------------------------
+// On return: w ascending eigenvalues, V columns = eigenvectors (row-major n x n).
+inline void jacobi_eigen(int n, const double* A_in, double* w, double* V) {
+  double A[81];
+  std::memcpy(A, A_in, sizeof(double) * n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i) {
+      diag += A[i * n + i] * A[i * n + i];
+      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+    }
+    if (off <= 1e-34 * diag || off == 0.0) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {   // A <- A G
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq;
+          A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {   // A <- G^T A
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk;
+          A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {   // V <- V G
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq;
+          V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int order[9];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::sort(order, order + n, [&](int a, int b) { return A[a * n + a] < A[b * n + b]; });
+  double Vs[81];
+  for (int k = 0; k < n; ++k) {
+    w[k] = A[order[k] * n + order[k]];
+    for (int i = 0; i < n; ++i) Vs[i * n + k] = V[i * n + order[k]];
+  }
+  std::memcpy(V, Vs, sizeof(double) * n * n);
+}
+
+inline double det3(const double* M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+inline void mul3(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// SVD of a 3x3 matrix: E = U diag(w) Vt, w descending, U and Vt orthogonal (row-major).
+inline void svd3(const double* E, double* U, double* w, double* Vt) {
+  double EtE[9], lam[3], V[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) EtE[3 * i + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+  jacobi_eigen(3, EtE, lam, V);                 // ascending
+  double Vd[9];                                  // columns reordered to descending singular values
+  for (int k = 0; k < 3; ++k) {
+    w[k] = std::sqrt(std::max(lam[2 - k], 0.0));
+    for (int i = 0; i < 3; ++i) Vd[3 * i + k] = V[3 * i + (2 - k)];
+  }
+  // U columns: u_k = E v_k / w_k for the two large singular values, u_2 = u_0 x u_1
+  double u[3][3];
+  for (int k = 0; k < 2; ++k) {
+    double n2 = 0;
+    for (int i = 0; i < 3; ++i) {
+      u[k][i] = E[3 * i] * Vd[k] + E[3 * i + 1] * Vd[3 + k] + E[3 * i + 2] * Vd[6 + k];
+      n2 += u[k][i] * u[k][i];
+    }
+    const double inv = n2 > 0 ? 1.0 / std::sqrt(n2) : 0.0;
+    for (int i = 0; i < 3; ++i) u[k][i] *= inv;
+  }
+  // re-orthogonalise u1 against u0 (guards the nearly-equal-singular-value case of an essential matrix)
+  double dot = u[0][0] * u[1][0] + u[0][1] * u[1][1] + u[0][2] * u[1][2];
+  double n2 = 0;
+  for (int i = 0; i < 3; ++i) { u[1][i] -= dot * u[0][i]; n2 += u[1][i] * u[1][i]; }
+  for (int i = 0; i < 3; ++i) u[1][i] /= std::sqrt(n2);
+  u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+  u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+  u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+  // keep E v_2 = w_2 u_2 consistent in sign
+  double ev2[3], s2 = 0;
+  for (int i = 0; i < 3; ++i) {
+    ev2[i] = E[3 * i] * Vd[2] + E[3 * i + 1] * Vd[5] + E[3 * i + 2] * Vd[8];
+    s2 += ev2[i] * u[2][i];
+  }
+  if (s2 < 0) for (int i = 0; i < 3; ++i) u[2][i] = -u[2][i];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) { U[3 * i + k] = u[k][i]; Vt[3 * k + i] = Vd[3 * i + k]; }
+}
+
+// cv::decomposeEssentialMat (OpenCV calib3d, call site .cpp:85): SVD, flip U / Vt to det +1,
+// R1 = U W Vt, R2 = U W^T Vt, t = last column of U.
+inline void decompose_essential(const double* E, double* R1, double* R2, double* t) {
+  double U[9], w[3], Vt[9];
+  svd3(E, U, w, Vt);
+  if (det3(U) < 0) for (double& v : U) v = -v;
+  if (det3(Vt) < 0) for (double& v : Vt) v = -v;
+  const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+  double T[9];
+  mul3(U, W, T); mul3(T, Vt, R1);
+  mul3(U, Wt, T); mul3(T, Vt, R2);
+  t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+}
+
+// rot2euler (.cpp:25-45): single-precision like the reference (float sy, float x/y/z, Vec3f).
+inline void rot_to_euler(const double* R, float out[3]) {
+  const float sy = static_cast<float>(std::sqrt(R[0] * R[0] + R[3] * R[3]));
+  if (!(sy < 1e-6f)) {
+    out[0] = static_cast<float>(std::atan2(R[7], R[8]));
+    out[1] = static_cast<float>(std::atan2(-R[6], static_cast<double>(sy)));
+    out[2] = static_cast<float>(std::atan2(R[3], R[0]));
+  } else {
+    out[0] = static_cast<float>(std::atan2(-R[5], R[4]));
+    out[1] = static_cast<float>(std::atan2(-R[6], static_cast<double>(sy)));
+    out[2] = 0.f;
+  }
+}
+
+// max_vec (.cpp:14-22), including its behaviour on ties.
+inline double max_vec(const float v[3]) {
+  if (v[0] > v[1] && v[0] > v[2]) return v[0];
+  if (v[1] > v[2]) return v[1];
+  return v[2];
+}
+
+struct Candidate {
+  float euler[3];
+  float tran[3];
+  int trial;
+  int which;   // 1 = R1, 2 = R2
+};
+
+inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// The groups trial `trial` draws: a partial Fisher-Yates shuffle of 0..63 seeded by (seed, trial).
+inline void trial_groups(uint64_t seed, int trial, int count, int* out) {
+  uint64_t s = seed * 0x2545F4914F6CDD1Dull + static_cast<uint64_t>(trial) * 0xD6E8FEB86659FD93ull + 1;
+  int perm[kGroups];
+  for (int i = 0; i < kGroups; ++i) perm[i] = i;
+  for (int i = 0; i < count; ++i) {
+    const int j = i + static_cast<int>(splitmix64(s) % static_cast<uint64_t>(kGroups - i));
+    std::swap(perm[i], perm[j]);
+    out[i] = perm[i];
+  }
+}
+
+// One trial from the summed moments (upper triangle, 45 values): E, its rank-2 projection, R1/R2/t, Euler angles.
+inline void trial_from_moments(const double* mom45, float e1[3], float e2[3], float tv[3], bool* v1, bool* v2,
+                               double* E_out /* 9, may be null */) {
+  double S[81], w[9], V[81];
+  int k = 0;
+  for (int a = 0; a < 9; ++a)
+    for (int b = a; b < 9; ++b) { S[9 * a + b] = S[9 * b + a] = mom45[k]; ++k; }
+  jacobi_eigen(9, S, w, V);
+  double E[9];
+  for (int i = 0; i < 9; ++i) E[i] = V[9 * i + 0];      // eigenvector of the smallest eigenvalue (.cpp:72-74)
+  // rank-2 correction: zero the smallest singular value (.cpp:75-80)
+  double U[9], sv[3], Vt[9], T[9], Ec[9];
+  svd3(E, U, sv, Vt);
+  const double D[9] = {sv[0], 0, 0, 0, sv[1], 0, 0, 0, 0};
+  mul3(U, D, T); mul3(T, Vt, Ec);
+  if (E_out) std::memcpy(E_out, Ec, sizeof(Ec));
+  double R1[9], R2[9], t[3];
+  decompose_essential(Ec, R1, R2, t);
+  rot_to_euler(R1, e1);
+  rot_to_euler(R2, e2);
+  for (int i = 0; i < 3; ++i) tv[i] = static_cast<float>(t[i]);
+  const float a1[3] = {std::fabs(e1[0]), std::fabs(e1[1]), std::fabs(e1[2])};
+  const float a2[3] = {std::fabs(e2[0]), std::fabs(e2[1]), std::fabs(e2[2])};
+  *v1 = max_vec(a1) < 1.57;                              // .cpp:103-115
+  *v2 = max_vec(a2) < 1.57;
+}
+
+// Consensus pick (.cpp:162-180): smallest 20-80 % trimmed mean of the distances to all candidates.
+inline int consensus_pick(const std::vector<Candidate>& c) {
+  const int r = static_cast<int>(c.size());
+  if (r == 0) return -1;
+  int best = 0;
+  double best_d = 0;
+  for (int i = 0; i < r; ++i) {
+    std::vector<double> d(r);
+    for (int j = 0; j < r; ++j) {
+      const float dx = c[i].euler[0] - c[j].euler[0], dy = c[i].euler[1] - c[j].euler[1], dz = c[i].euler[2] - c[j].euler[2];
+      d[j] = std::sqrt(static_cast<double>(dx * dx + dy * dy + dz * dz));
+    }
+    std::sort(d.begin(), d.end());
+    const int lo = static_cast<int>(r * 0.2), hi = static_cast<int>(r * 0.8);
+    double acc = 0.0;
+    for (int j = lo; j < hi; ++j) acc += d[j];
+    const double avg = acc / (static_cast<double>(hi - lo) * 1.0);    // 0/0 = NaN for r < 2, as in the reference
+    if (i == 0 || avg < best_d) { best = i; best_d = avg; }          // std::min_element keeps the first minimum
+  }
+  return best;
+}
+
+struct GuessResult {
+  float euler[3] = {0, 0, 0};   // R_vec_out
+  float tran[3] = {0, 0, 0};    // T_vec_out
+  int num_candidates = 0;
+  int picked = -1;
+  std::vector<Candidate> candidates;
+};
+
+// groups: [64][45] moments, counts not needed.  trials / fraction / seed: 80, 0.25 in the reference.
+inline GuessResult initial_guess_from_groups(const double* groups, int trials, double fraction, uint64_t seed) {
+  GuessResult res;
+  const int take = std::max(1, std::min(kGroups, static_cast<int>(kGroups * fraction)));
+  for (int trial = 0; trial < trials; ++trial) {
+    int sel[kGroups];
+    trial_groups(seed, trial, take, sel);
+    std::sort(sel, sel + take);                     // fixed summation order
+    double mom[kMom] = {0};
+    for (int s = 0; s < take; ++s)
+      for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
+    Candidate c1{}, c2{};
+    bool v1 = false, v2 = false;
+    float tv[3];
+    trial_from_moments(mom, c1.euler, c2.euler, tv, &v1, &v2, nullptr);
+    for (int i = 0; i < 3; ++i) c1.tran[i] = c2.tran[i] = tv[i];
+    c1.trial = c2.trial = trial; c1.which = 1; c2.which = 2;
+    if (v1) res.candidates.push_back(c1);            // .cpp:148-157: T_vec is pushed with either rotation
+    if (v2) res.candidates.push_back(c2);
+  }
+  res.num_candidates = static_cast<int>(res.candidates.size());
+  res.picked = consensus_pick(res.candidates);
+  if (res.picked >= 0) {
+    std::memcpy(res.euler, res.candidates[res.picked].euler, sizeof(res.euler));
+    std::memcpy(res.tran, res.candidates[res.picked].tran, sizeof(res.tran));
+  }
+  return res;
+}
+
+}  // namespace epi
+}  // namespace sba

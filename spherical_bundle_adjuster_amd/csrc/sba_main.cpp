@@ -32,6 +32,8 @@ int main(int argc, char** argv) {
   spherical_bundle_adjuster sph_ba(atof(argv[3]), atof(argv[4]), atof(argv[5]), atof(argv[6]), atof(argv[7]),
                                    atof(argv[8]), atof(argv[9]));
   sph_ba.set_omp(1);
+  // SBA_INITIAL_GUESS=0: start from the expected values on the command line instead of the 8-point consensus
+  if (const char* env = std::getenv("SBA_INITIAL_GUESS")) sph_ba.set_initial_guess(env[0] != '0');
   std::vector<cv::KeyPoint> left_key, right_key;
   int w = 0, h = 0, w2 = 0, h2 = 0;
   if (!read_keypoints(argv[1], &left_key, &w, &h) || !read_keypoints(argv[2], &right_key, &w2, &h2) ||

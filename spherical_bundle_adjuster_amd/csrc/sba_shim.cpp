@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sba_device.hpp"
+#include "sba_epipolar.hpp"
 #include "sba_internal.hpp"
 #include "sba_lm.hpp"
 #include "sba_rotation.hpp"
@@ -468,6 +469,28 @@ int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const vo
   return upload_common(p, left_xyz_dev, right_xyz_dev, d12_dev, n, store, true);
 }
 
+int sba_problem_set_depths(sba_problem* p, const double* d12) {
+  if (!p || !d12) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  if (!p->has_d12) {
+    for (auto& d : p->dplane) {
+      SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), std::max<size_t>(p->plane_elems, 1) * 8));
+      SBA_HIP_TRY(hipMemsetAsync(d, 0, std::max<size_t>(p->plane_elems, 1) * 8, p->stream));
+    }
+    p->has_d12 = true;
+  }
+  if (p->n > 0) {
+    double* stage = nullptr;
+    SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage), p->n * 2 * sizeof(double)));
+    SBA_HIP_TRY(hipMemcpyAsync(stage, d12, p->n * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    SBA_HIP_TRY(sba::launch_d12_to_planes(stage, p->n, 0, p->dplane[0], p->dplane[1], p->stream));
+    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    SBA_HIP_TRY(hipFree(stage));
+  }
+  return SBA_OK;
+}
+
 int sba_problem_set_kernel(sba_problem* p, int kind) {
   if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
   if (kind != SBA_KERNEL_FACTORED && kind != SBA_KERNEL_EXPLICIT) return fail(SBA_ERR_INVALID_ARG, "bad kernel kind %d", kind);
@@ -756,6 +779,48 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   cleanup();
   if (rc_final != SBA_OK) return fail(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
   return SBA_OK;
+}
+
+// ---- 8-point initial guess (reference .cpp:47-181) -------------------------------------------------------
+int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
+  if (!p || !groups) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  const size_t nquad = (p->n + 3) / 4;
+  const int grid = static_cast<int>(std::min<size_t>((nquad + 63) / 64, static_cast<size_t>(p->num_cus) * 4));
+  double *partials = nullptr, *groups_dev = nullptr;
+  const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&partials), static_cast<size_t>(std::max(grid, 1)) * gsz * sizeof(double)));
+  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&groups_dev), gsz * sizeof(double)));
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+  SBA_HIP_TRY(sba::launch_epipolar_moments(p->store, pl, p->n, partials, grid, groups_dev, p->stream));
+  SBA_HIP_TRY(hipMemcpyAsync(groups, groups_dev, gsz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  SBA_HIP_TRY(hipFree(partials));
+  SBA_HIP_TRY(hipFree(groups_dev));
+  return SBA_OK;
+}
+
+int sba_initial_guess_from_moments(const double* groups, int trials, double subset_fraction, unsigned long long seed,
+                                   double rot_euler[3], double tran[3], int* num_candidates) {
+  if (!groups || !rot_euler || !tran) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (trials < 1 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
+    return fail(SBA_ERR_INVALID_ARG, "bad trials / subset_fraction");
+  const sba::epi::GuessResult r = sba::epi::initial_guess_from_groups(groups, trials, subset_fraction, seed);
+  if (num_candidates) *num_candidates = r.num_candidates;
+  if (r.picked < 0) return fail(SBA_ERR_NUMERIC, "no valid rotation candidate (all Euler angles >= 1.57)");
+  for (int i = 0; i < 3; ++i) { rot_euler[i] = r.euler[i]; tran[i] = r.tran[i]; }
+  return SBA_OK;
+}
+
+int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction, unsigned long long seed,
+                              double rot_euler[3], double tran[3], int* num_candidates) {
+  std::vector<double> groups(static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom);
+  const int rc = sba_problem_epipolar_moments(p, groups.data());
+  if (rc) return rc;
+  return sba_initial_guess_from_moments(groups.data(), trials, subset_fraction, seed, rot_euler, tran, num_candidates);
 }
 
 static int require_device(int device) {

@@ -55,14 +55,35 @@ int spherical_bundle_adjuster::do_bundle_adjustment_from_matches(const std::vect
   if (rc) return rc;
 
   std::cout << "Do bundle adjustment" << std::endl;                                     // .cpp:300
-  // Initial values.  The reference takes them from its 8-point consensus (initial_guess, .cpp:304,
-  // :330-331: init_rot = -Euler, init_tran = T); that stage is the next row of the scope table
-  // (SURVEY.md 8f-1).  Until it lands the expected values given on the command line are used, which is
-  // the alternative the reference itself keeps in a comment (.cpp:328-329).
+  // The coordinates go to the device once; the initial guess and all three solve stages work on that copy.
+  if (!problem) {
+    rc = sba_problem_create(&problem, device, nullptr);
+    if (rc) return rc;
+  }
+  rc = sba_problem_upload(problem, reinterpret_cast<const double*>(key_point_left_rect.data()),
+                          reinterpret_cast<const double*>(key_point_right_rect.data()), nullptr,
+                          static_cast<size_t>(match_size), SBA_STORE_F64);
+  if (rc) return rc;
+  resident_left = key_point_left_rect.data();
+  resident_n = match_size;
+
+  // Initial values (.cpp:302-331).  Default: the 8-point consensus (initial_guess, .cpp:304), then
+  // init_rot = -Euler(R_vec_out) and init_tran = T_vec_out exactly like .cpp:330-331 -- including the reference's
+  // use of the negated Euler triple as an angle-axis vector.  set_initial_guess(false) starts from the expected
+  // values given on the command line instead, the alternative the reference keeps in a comment (.cpp:328-329).
   std::vector<std::array<double, 2>> init_d(match_size);
   for (auto& d : init_d) d = {expected_d, expected_d};                                   // .cpp:325-326
   double init_rot[3] = {expected_roll / 180 * kPi, expected_pitch / 180 * kPi, expected_yaw / 180 * kPi};
   double init_tran[3] = {expected_tx, expected_ty, expected_tz};
+  if (use_initial_guess) {
+    std::cout << "E matrix estimation with SVD" << std::endl;                           // .cpp:127
+    double euler[3], tvec[3];
+    int candidates = 0;
+    rc = sba_problem_initial_guess(problem, 80, 0.25, guess_seed, euler, tvec, &candidates);   // .cpp:130-133
+    if (rc) return rc;
+    for (int i = 0; i < 3; ++i) { init_rot[i] = -euler[i]; init_tran[i] = tvec[i]; }     // .cpp:330-331
+    res.guess_candidates = candidates;
+  }
 
   sba_lm_options options;
   sba_lm_options_default(&options);
@@ -93,11 +114,16 @@ int spherical_bundle_adjuster::solve_problem(sba_lm_options& opt, std::vector<cv
     if (rc) return rc;
   }
   // One flat upload replaces the per-match `new AutoDiffCostFunction / new HuberLoss` of the four
-  // add_residual loops (.cpp:870-889, :921-945, :978-1002, :1034-1063).
-  rc = sba_problem_upload(problem, reinterpret_cast<const double*>(key_point_left_rect.data()),
-                          reinterpret_cast<const double*>(key_point_right_rect.data()),
-                          match_num > 0 ? reinterpret_cast<const double*>(init_d.data()) : nullptr,
-                          static_cast<size_t>(match_num), SBA_STORE_F64);
+  // add_residual loops (.cpp:870-889, :921-945, :978-1002, :1034-1063).  When do_bundle_adjustment_from_matches
+  // already made these coordinates resident, only the depths (init_d) are sent.
+  if (resident_left == key_point_left_rect.data() && resident_n == match_num && match_num > 0) {
+    rc = sba_problem_set_depths(problem, reinterpret_cast<const double*>(init_d.data()));
+  } else {
+    rc = sba_problem_upload(problem, reinterpret_cast<const double*>(key_point_left_rect.data()),
+                            reinterpret_cast<const double*>(key_point_right_rect.data()),
+                            match_num > 0 ? reinterpret_cast<const double*>(init_d.data()) : nullptr,
+                            static_cast<size_t>(match_num), SBA_STORE_F64);
+  }
   if (rc) return rc;
 
   auto report = [](const char* stage, const sba_lm_summary& s) {

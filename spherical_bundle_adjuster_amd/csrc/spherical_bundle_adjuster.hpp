@@ -37,6 +37,8 @@ class spherical_bundle_adjuster {
   void set_matcher(matcher_fn fn) { matcher = std::move(fn); }
   void set_device(int hip_device) { device = hip_device; }
   void set_log_path(const std::string& path) { log_path = path; }   // default "log.txt" (.cpp:349)
+  // true (default, like the reference): start from the 8-point consensus; false: from the expected values.
+  void set_initial_guess(bool on, unsigned long long seed = 0) { use_initial_guess = on; guess_seed = seed; }
   // Everything after the matcher: pixel -> sphere, initial values, three-stage solve, log row.
   // Returns 0 or a negative SBA_ERR_* (message via sba_last_error()).
   int do_bundle_adjustment_from_matches(const std::vector<cv::KeyPoint>& left_key,
@@ -47,6 +49,7 @@ class spherical_bundle_adjuster {
     double tran[3] = {0, 0, 0};   // init_tran after solve_problem
     int match_size = 0;
     sba_lm_summary depth_stage{}, rot_stage{}, tran_stage{};
+    int guess_candidates = 0;     // valid rotation candidates of the 8-point consensus
   };
   const result& last_result() const { return res; }
 
@@ -61,6 +64,10 @@ class spherical_bundle_adjuster {
   int device = 0;
   std::string log_path = "log.txt";
   matcher_fn matcher;
+  bool use_initial_guess = true;
+  unsigned long long guess_seed = 0;
+  const void* resident_left = nullptr;   // coordinates currently resident in `problem`
+  int resident_n = -1;
   sba_problem* problem = nullptr;
   result res;
 };

@@ -1,0 +1,15 @@
+// TEST HARNESS (tests/ only): exposes the product's host-side 8-point math (csrc/sba_epipolar.hpp).
+#include "../../spherical_bundle_adjuster_amd/csrc/sba_epipolar.hpp"
+using namespace sba::epi;
+extern "C" {
+void harness_jacobi(int n, const double* A, double* w, double* V) { jacobi_eigen(n, A, w, V); }
+void harness_svd3(const double* E, double* U, double* w, double* Vt) { svd3(E, U, w, Vt); }
+void harness_decompose(const double* E, double* R1, double* R2, double* t) { decompose_essential(E, R1, R2, t); }
+void harness_euler(const double* R, float* out) { rot_to_euler(R, out); }
+void harness_trial_groups(unsigned long long seed, int trial, int count, int* out) { trial_groups(seed, trial, count, out); }
+void harness_trial(const double* mom45, float* e1, float* e2, float* tv, int* v1, int* v2, double* E) {
+  bool a, b;
+  trial_from_moments(mom45, e1, e2, tv, &a, &b, E);
+  *v1 = a; *v2 = b;
+}
+}

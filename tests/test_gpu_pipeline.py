@@ -41,7 +41,9 @@ def test_cli_three_stage_pipeline(oracle, tmp_path):
     exp_d = 6.0
     args = [str(SBA_MAIN), str(tmp_path / "left.kp"), str(tmp_path / "right.kp"), *(f"{v:.17g}" for v in deg),
             *(f"{v:.17g}" for v in c.tran_init), f"{exp_d}"]
-    r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    import os
+    r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, SBA_INITIAL_GUESS="0"))       # start from the expected values (.cpp:328-329)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "rotation vector in degree" in r.stdout and "translation vector" in r.stdout and "Done." in r.stdout
     row = (tmp_path / "log.txt").read_text().strip().split(",")
@@ -68,3 +70,36 @@ def test_cli_usage_and_errors(tmp_path):
     assert r.returncode == 0 and "usage" in r.stdout     # the reference returns 0 on a usage error (main/main.cpp:11)
     r = subprocess.run([str(SBA_MAIN), "nope", "nope", *["0"] * 7], capture_output=True, text=True, timeout=30)
     assert r.returncode != 0
+
+
+def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
+    """Default path like the reference: 8-point consensus -> init_rot = -Euler, init_tran = T (.cpp:304, :330-331),
+    then d-only -> rot-only -> tran-only.  Checked against the same stages driven through the Python binding and
+    the oracle from the SAME initial values."""
+    from spherical_bundle_adjuster_amd import api
+    W, H, n = 3840, 1920, 4096
+    c = synthetic.full_rt(n, seed=synthetic.BASE_SEED + 9, sigma=2e-4, outlier_fraction=0.02)
+    lx, ly = _sphere_to_pixels(c.x1, W, H)
+    rx, ry = _sphere_to_pixels(c.x2, W, H)
+    kl = _write_keypoints(tmp_path / "left.kp", lx, ly, W, H)
+    kr = _write_keypoints(tmp_path / "right.kp", rx, ry, W, H)
+    exp_d = 6.0
+    args = [str(SBA_MAIN), str(tmp_path / "left.kp"), str(tmp_path / "right.kp"), "0", "0", "0", "0", "0", "0", f"{exp_d}"]
+    r = subprocess.run(args, cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "E matrix estimation with SVD" in r.stdout
+    row = (tmp_path / "log.txt").read_text().strip().split(",")
+    got_rot = np.deg2rad([float(v) for v in row[3:6]]); got_tran = np.array([float(v) for v in row[6:9]])
+    x1 = oracle.keypoints_to_sphere(kl, W, H); x2 = oracle.keypoints_to_sphere(kr, W, H)
+    with api.Problem(0) as p:
+        p.upload(x1, x2)
+        e, t, ncand = p.initial_guess(80, 0.25, 0)
+    assert ncand > 40
+    rot0, tran0 = -e, t
+    d, _, rc = oracle.depth_solve(x1, x2, rot0, tran0, np.full((n, 2), exp_d))
+    r1, t1, _, _ = oracle.lm_solve(0, x1, x2, rot0, tran0, d[0, 0], d[1, 0])
+    r2, t2, _, _ = oracle.lm_solve(1, x1, x2, r1, t1, d[0, 0], d[1, 0])
+    assert np.abs(got_rot - r2).max() < 2e-6 * max(1, np.abs(r2).max()) + 1e-7
+    assert np.abs(got_tran - t2).max() < 2e-5 * max(1, np.abs(t2).max())
+    # and the guess itself is in the neighbourhood of the true rotation
+    assert np.abs(rot0 - c.rot_true).max() < 0.2

@@ -62,3 +62,37 @@ def test_rccl_single_rank_and_hook():
         assert np.array_equal(p.eval_pack(api.MODE_ROT, c.rot_init, c.tran_init), base)
         r, t, s = p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
         assert s.termination.startswith("CONVERGENCE")
+
+
+@pytest.mark.parametrize("n,store", [(1, api.STORE_F64), (255, api.STORE_F64), (256, api.STORE_F64), (257, api.STORE_F64),
+                                     (100003, api.STORE_F64), (100003, api.STORE_F32)])
+def test_epipolar_moments_vs_numpy(n, store):
+    """Device pass of the 8-point initial guess: per-group A^T A of the kron(left, right) rows (.cpp:53-68)."""
+    from test_initial_guess_cpu import group_moments
+    c = synthetic.full_rt(n, seed=800 + n)
+    x1, x2 = (c.x1, c.x2) if store == api.STORE_F64 else (c.x1.astype(np.float32).astype(np.float64),
+                                                          c.x2.astype(np.float32).astype(np.float64))
+    ref, _, _ = group_moments(x1, x2)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, store=store)
+        got = p.epipolar_moments()
+        assert np.abs(got - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300)
+        assert np.array_equal(got, p.epipolar_moments())            # fixed fold order: bit-identical
+        if n >= 100000:
+            e, t, ncand = p.initial_guess(80, 0.25, 3)
+            e2, t2, n2 = api.initial_guess_from_moments(got, 80, 0.25, 3)
+            assert np.array_equal(e, e2) and np.array_equal(t, t2) and ncand == n2
+
+
+def test_set_depths(oracle):
+    c = synthetic.full_rt(3000, seed=77)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2)                       # coordinates only
+        p.set_depths(c.d12)
+        got = p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        ref = oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12)
+        assert np.abs(got.H - ref.H).max() <= 1e-12 * np.abs(ref.H).max()
+        p.set_depths(2 * c.d12)                    # replace
+        got2 = p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        ref2 = oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=2 * c.d12)
+        assert np.abs(got2.H - ref2.H).max() <= 1e-12 * np.abs(ref2.H).max()

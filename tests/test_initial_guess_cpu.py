@@ -1,0 +1,131 @@
+"""CPU: host side of the 8-point initial guess (csrc/sba_epipolar.hpp, reference .cpp:47-181) against numpy:
+Jacobi eigen / 3x3 SVD / decomposeEssentialMat restatement, one trial against an explicit A + numpy SVD, and the
+known answer on clean data.  The C-ABI entry sba_initial_guess_from_moments needs no device."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+from spherical_bundle_adjuster_amd import api, synthetic
+
+_h = None
+
+
+def harness():
+    global _h
+    if _h is None:
+        so = ROOT / "tests" / "harness" / "libepi_harness.so"
+        src = ROOT / "tests" / "harness" / "epi_harness.cpp"
+        hdr = ROOT / "spherical_bundle_adjuster_amd" / "csrc" / "sba_epipolar.hpp"
+        if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(src)], check=True)
+        _h = C.CDLL(str(so))
+    return _h
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def group_moments(x1, x2):
+    """numpy reference of the device pass: per group (i//4) % 64 the upper triangle of A^T A, A rows = kron(l, r)."""
+    n = len(x1)
+    A = (x1[:, :, None] * x2[:, None, :]).reshape(n, 9)            # .cpp:59-67
+    grp = (np.arange(n) // 4) % 64
+    iu = np.triu_indices(9)
+    out = np.zeros((64, 45))
+    for g in range(64):
+        a = A[grp == g]
+        out[g] = (a.T @ a)[iu]
+    return out, A, grp
+
+
+def euler_of(R):
+    sy = np.hypot(R[0, 0], R[1, 0])
+    return np.array([np.arctan2(R[2, 1], R[2, 2]), np.arctan2(-R[2, 0], sy), np.arctan2(R[1, 0], R[0, 0])])
+
+
+def test_jacobi_and_svd3_vs_numpy():
+    rng = np.random.default_rng(0)
+    for n in (3, 9):
+        for _ in range(10):
+            M = rng.standard_normal((n + 4, n)); S = M.T @ M
+            w, V = np.zeros(n), np.zeros((n, n))
+            harness().harness_jacobi(C.c_int(n), _p(S), _p(w), _p(V))
+            wn = np.linalg.eigvalsh(S)
+            assert np.abs(w - wn).max() <= 1e-12 * wn.max()
+            assert np.abs(V.T @ V - np.eye(n)).max() < 1e-13 and np.abs(S @ V - V * w).max() <= 1e-12 * wn.max()
+    for _ in range(20):
+        E = rng.standard_normal((3, 3))
+        U, w, Vt = np.zeros((3, 3)), np.zeros(3), np.zeros((3, 3))
+        harness().harness_svd3(_p(E), _p(U), _p(w), _p(Vt))
+        assert np.abs(U @ np.diag(w) @ Vt - E).max() < 1e-13 and np.abs(w - np.linalg.svd(E, compute_uv=False)).max() < 1e-13
+        assert np.abs(U.T @ U - np.eye(3)).max() < 1e-13 and np.abs(Vt @ Vt.T - np.eye(3)).max() < 1e-13 and w[0] >= w[1] >= w[2]
+
+
+def test_decompose_essential_recovers_motion():
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        w = synthetic._true_rotation(rng); R = synthetic.rodrigues(w)
+        t = synthetic._unit(rng.standard_normal(3))
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        R1, R2, tt = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+        harness().harness_decompose(_p(E), _p(R1), _p(R2), _p(tt))
+        assert min(np.abs(R1 - R).max(), np.abs(R2 - R).max()) < 1e-12
+        assert min(np.abs(tt - t).max(), np.abs(tt + t).max()) < 1e-12
+        for Rk in (R1, R2):
+            assert abs(np.linalg.det(Rk) - 1) < 1e-12 and np.abs(Rk @ Rk.T - np.eye(3)).max() < 1e-12
+        e = np.zeros(3, dtype=np.float32)
+        harness().harness_euler(_p(R), _p(e))
+        assert np.abs(e - euler_of(R)).max() < 1e-6          # single precision like rot2euler (.cpp:25-45)
+
+
+def test_one_trial_vs_explicit_A_and_numpy_svd():
+    """A trial from summed group moments == the reference recipe on the explicit subset matrix A (numpy SVD)."""
+    c = synthetic.full_rt(4096, seed=12, sigma=5e-4, outlier_fraction=0.0)
+    G, A, grp = group_moments(c.x1, c.x2)
+    sel = np.zeros(16, dtype=np.int32)
+    harness().harness_trial_groups(C.c_ulonglong(5), C.c_int(3), C.c_int(16), _p(sel))
+    assert len(set(sel.tolist())) == 16 and sel.min() >= 0 and sel.max() < 64
+    mom = G[np.sort(sel)].sum(0)
+    e1, e2, tv = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    v1, v2, Ec = C.c_int(0), C.c_int(0), np.zeros((3, 3))
+    harness().harness_trial(_p(mom), _p(e1), _p(e2), _p(tv), C.byref(v1), C.byref(v2), _p(Ec))
+    # reference recipe (.cpp:53-85) on the explicit rows
+    As = A[np.isin(grp, sel)]
+    E = np.linalg.svd(As)[2][-1].reshape(3, 3)
+    U, s, Vt = np.linalg.svd(E)
+    Ec_ref = U @ np.diag([s[0], s[1], 0.0]) @ Vt
+    assert min(np.abs(Ec - Ec_ref).max(), np.abs(Ec + Ec_ref).max()) < 1e-9          # null vector sign is free
+    if np.linalg.det(U) < 0: U = -U
+    if np.linalg.det(Vt) < 0: Vt = -Vt
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    cands = [euler_of(U @ W @ Vt), euler_of(U @ W.T @ Vt)]
+    for e in (e1, e2):      # {R1, R2} as a set
+        assert min(np.abs(e - cands[0]).max(), np.abs(e - cands[1]).max()) < 1e-5
+    assert min(np.abs(tv - U[:, 2]).max(), np.abs(tv + U[:, 2]).max()) < 1e-5
+
+
+def test_initial_guess_known_answer_and_determinism():
+    c = synthetic.full_rt(20000, seed=13, sigma=0.0, outlier_fraction=0.0)
+    G, _, _ = group_moments(c.x1, c.x2)
+    e, t, ncand = api.initial_guess_from_moments(G, 80, 0.25, seed=1)
+    # left^T E right = 0 with x2 ~ R x1 - t  =>  the recovered rotation is R^T and T = +-R^T t
+    Rt = synthetic.rodrigues(c.rot_true).T
+    assert np.abs(e - euler_of(Rt)).max() < 1e-5 and ncand >= 80
+    tt = Rt @ c.tran_true
+    assert min(np.abs(t - tt).max(), np.abs(t + tt).max()) < 1e-5
+    # the reference starts from init_rot = -Euler (.cpp:330): close to the true angle-axis for moderate rotations
+    assert np.abs(-e - c.rot_true).max() < 0.15
+    e2, t2, n2 = api.initial_guess_from_moments(G, 80, 0.25, seed=1)
+    assert np.array_equal(e, e2) and np.array_equal(t, t2) and n2 == ncand
+    # noisy data with outliers: the consensus still lands near the truth
+    c = synthetic.full_rt(20000, seed=14)
+    G, _, _ = group_moments(c.x1, c.x2)
+    e, t, _ = api.initial_guess_from_moments(G, 80, 0.25, seed=2)
+    assert np.abs(e - euler_of(synthetic.rodrigues(c.rot_true).T)).max() < 0.1
+    with pytest.raises(api.SbaError):
+        api.initial_guess_from_moments(G, 0, 0.25)
