@@ -313,6 +313,21 @@ int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, i
 int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
                          int cube_size, int batch, void* out_dev);
 
+/* ---- key-point / image maps of the matchers (what turns matcher output into the BA path's input) ------ */
+/* spherical_surf::rotate_keypoint (spherical_surf.cpp:110-123): in place on n records of stride_bytes whose
+ * first two floats are pt.x, pt.y (band coordinates); adds the band offset H*3/8, rotates by the pitch angle
+ * through rotate_pixel (:48-74) with the reference's integer truncations, writes ERP pixel coordinates back. */
+int sba_rotate_keypoints(int device, void* keypoints, size_t n, size_t stride_bytes, float pitch_deg,
+                         int im_width, int im_height);
+/* equi2cube_surf::cube2equi_pixel (equi2cube_surf.cpp:19-76): in place, cube-strip pixel -> ERP pixel.       */
+int sba_cube2equi_keypoints(int device, void* keypoints, size_t n, size_t stride_bytes, int cube_size,
+                            int im_width, int im_height);
+/* spherical_surf::crop_rotated_image (spherical_surf.cpp:76-108): erp H x W x 3 bytes -> out (H/4) x W x 3,
+ * the equatorial band of the image rotated by pitch_deg (inverse warping); pixels whose source falls outside
+ * the image are 0 (the reference leaves them uninitialised).                                               */
+int sba_crop_rotated_image(int device, const uint8_t* erp, int im_height, int im_width, float pitch_deg,
+                           uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

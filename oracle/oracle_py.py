@@ -174,3 +174,24 @@ def equi2cube(im: np.ndarray, cube: int, clamp: bool = True):
     clamped = lib().orc_equi2cube(_p(im), C.c_int(im.shape[0]), C.c_int(im.shape[1]), C.c_int(cube),
                                   C.c_int(1 if clamp else 0), _p(out))
     return out, int(clamped)
+
+
+def rotate_keypoints(kp: np.ndarray, pitch_deg: float, im_w: int, im_h: int) -> np.ndarray:
+    kp = np.ascontiguousarray(kp).copy()
+    lib().orc_rotate_keypoints(_p(kp), C.c_size_t(kp.shape[0]), C.c_size_t(kp.strides[0] if kp.shape[0] else 28),
+                               C.c_float(pitch_deg), C.c_int(im_w), C.c_int(im_h))
+    return kp
+
+
+def cube2equi_keypoints(kp: np.ndarray, cube: int, im_w: int, im_h: int) -> np.ndarray:
+    kp = np.ascontiguousarray(kp).copy()
+    lib().orc_cube2equi_keypoints(_p(kp), C.c_size_t(kp.shape[0]), C.c_size_t(kp.strides[0] if kp.shape[0] else 28),
+                                  C.c_int(cube), C.c_int(im_w), C.c_int(im_h))
+    return kp
+
+
+def crop_rotated_image(im: np.ndarray, pitch_deg: float) -> np.ndarray:
+    im = np.ascontiguousarray(im, dtype=np.uint8)
+    out = np.zeros((im.shape[0] // 4, im.shape[1], 3), dtype=np.uint8)
+    lib().orc_crop_rotated_image(_p(im), C.c_int(im.shape[0]), C.c_int(im.shape[1]), C.c_float(pitch_deg), _p(out))
+    return out

@@ -602,6 +602,80 @@ void orc_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride, int im_
   }
 }
 
+// ---- key-point coordinate maps of the matchers -------------------------------------------------------------
+// eular2rot(Vec3f(0, RAD(pitch), 0)) (spherical_surf.cpp:18-45, call sites :84, :112): theta is a float, and
+// with <cmath> + `using namespace std` cos/sin of a float are the float overloads; R_x = R_z = I, so R = R_y.
+static void pitch_rotation(float pitch_deg, double R[9]) {
+  const float th = static_cast<float>(M_PI * pitch_deg / 180.0);
+  const double c = std::cos(th), s = std::sin(th);   // std::cos(float) -> float, widened
+  const double Ry[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
+  std::memcpy(R, Ry, sizeof(Ry));
+}
+// rotate_pixel (spherical_surf.cpp:48-74): (row, col) ints -> sphere -> rotate -> (row, col) ints by truncation.
+static void rotate_pixel_ref(int row, int col, const double R[9], int width, int height, int* out_row, int* out_col) {
+  const double r0 = M_PI * row / height, r1 = 2 * M_PI * col / width;
+  const double v[3] = {std::sin(r0) * std::cos(r1), std::sin(r0) * std::sin(r1), std::cos(r0)};
+  const double w[3] = {R[0] * v[0] + R[1] * v[1] + R[2] * v[2], R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+                       R[6] * v[0] + R[7] * v[1] + R[8] * v[2]};
+  const double a = std::acos(w[2]);
+  double b = std::atan2(w[1], w[0]);
+  if (b < 0) b += M_PI * 2;
+  *out_row = static_cast<int>(height * a / M_PI);
+  *out_col = static_cast<int>(width * b / (2 * M_PI));
+}
+// rotate_keypoint (spherical_surf.cpp:110-123), in place on records whose first two floats are pt.x, pt.y.
+void orc_rotate_keypoints(uint8_t* kp, size_t n, size_t stride, float pitch_deg, int width, int height) {
+  double R[9];
+  pitch_rotation(pitch_deg, R);
+  for (size_t i = 0; i < n; ++i) {
+    float px, py;
+    std::memcpy(&px, kp + i * stride, 4);
+    std::memcpy(&py, kp + i * stride + 4, 4);
+    const int offset_i = static_cast<int>(py + height * 3 / 8);     // float + int, truncated (.cpp:116)
+    int r, c;
+    rotate_pixel_ref(offset_i, static_cast<int>(px), R, width, height, &r, &c);
+    px = static_cast<float>(c); py = static_cast<float>(r);
+    std::memcpy(kp + i * stride, &px, 4);
+    std::memcpy(kp + i * stride + 4, &py, 4);
+  }
+}
+// crop_rotated_image (spherical_surf.cpp:76-108): (H/4) x W band; pixels whose source falls outside stay 0 here
+// (the reference leaves them uninitialised).
+void orc_crop_rotated_image(const uint8_t* im, int im_h, int im_w, float pitch_deg, uint8_t* out) {
+  double R[9];
+  pitch_rotation(pitch_deg, R);
+  std::memset(out, 0, static_cast<size_t>(im_h / 4) * im_w * 3);
+  for (int i = 0; i < im_h / 4; ++i)
+    for (int j = 0; j < im_w; ++j) {
+      int r, c;
+      rotate_pixel_ref(i + im_h * 3 / 8, j, R, im_w, im_h, &r, &c);
+      if (r >= 0 && c >= 0 && r < im_h && c < im_w)
+        std::memcpy(out + (static_cast<size_t>(i) * im_w + j) * 3, im + (static_cast<size_t>(r) * im_w + c) * 3, 3);
+    }
+}
+// cube2equi_pixel (equi2cube_surf.cpp:19-76), in place on key-point records (pt in the 6S x S cube strip).
+void orc_cube2equi_keypoints(uint8_t* kp, size_t n, size_t stride, int S, int im_w, int im_h) {
+  for (size_t i = 0; i < n; ++i) {
+    float cx, cy;
+    std::memcpy(&cx, kp + i * stride, 4);
+    std::memcpy(&cy, kp + i * stride + 4, 4);
+    double v[3] = {0, 0, 0};
+    if (cx < S) { v[0] = (S - 2.0 * cx) / S; v[1] = 1.0; v[2] = (S - 2.0 * cy) / S; }                                   // left
+    else if (cx >= S && cx < 2 * S) { v[0] = -1.0; v[1] = (S - 2.0 * (cx - S)) / S; v[2] = (S - 2.0 * cy) / S; }         // front
+    else if (cx >= 2 * S && cx < 3 * S) { v[0] = (2.0 * (cx - 2 * S) - S) / S; v[1] = -1.0; v[2] = (S - 2.0 * cy) / S; } // right
+    else if (cx >= 3 * S && cx < 4 * S) { v[0] = 1.0; v[1] = (2.0 * (cx - 3 * S) - S) / S; v[2] = (S - 2.0 * cy) / S; }  // back
+    else if (cx >= 4 * S && cx < 5 * S) { v[0] = (S - 2.0 * cy) / S; v[1] = (S - 2.0 * (cx - 4 * S)) / S; v[2] = 1.0; }  // top
+    else if (cx >= 5 * S) { v[0] = (2.0 * cy - S) / S; v[1] = (S - 2.0 * (cx - 5 * S)) / S; v[2] = -1.0; }               // bottom
+    const double nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double a = std::acos(v[2] / nrm);
+    double b = std::atan2(v[1] / nrm, v[0] / nrm);
+    if (b < 0) b += M_PI * 2;
+    const float ex = static_cast<float>(im_w * b / (2 * M_PI)), ey = static_cast<float>(im_h * a / M_PI);
+    std::memcpy(kp + i * stride, &ex, 4);
+    std::memcpy(kp + i * stride + 4, &ey, 4);
+  }
+}
+
 // ---- ERP -> cubemap strip, equi2cube.cpp:12-302 -----------------------------------------------------
 // face order of get_all (equi2cube.cpp:292-298): left, front, right, back, top, bottom.  `clamp` != 0
 // clamps the source index into the image (the reference does not, equi2cube.cpp:47-50); the number of

@@ -117,6 +117,9 @@ SIGNATURES = {
     "sba_batch_solve": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(LmOptions),
                                   C.POINTER(LmSummary), C.POINTER(C.c_int)]),
     "sba_keypoints_to_sphere": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),
+    "sba_rotate_keypoints": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_int]),
+    "sba_cube2equi_keypoints": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "sba_crop_rotated_image": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp]),
     "sba_equi2cube": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "sba_equi2cube_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
 }

@@ -377,3 +377,34 @@ def equi2cube(erp: np.ndarray, cube_size: int, device: int = 0) -> np.ndarray:
     cabi.check(lib, lib.sba_equi2cube(device, im.ctypes.data_as(C.c_void_p), im.shape[0], im.shape[1], cube_size,
                                       out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def _kp_inplace(fn, keypoints: np.ndarray, *args, device: int = 0) -> np.ndarray:
+    lib = cabi.load_library()
+    kp = np.ascontiguousarray(keypoints).copy()
+    n = kp.shape[0]
+    stride = kp.strides[0] if n > 0 else 28
+    cabi.check(lib, getattr(lib, fn)(device, kp.ctypes.data_as(C.c_void_p), n, stride, *args))
+    return kp
+
+
+def rotate_keypoints(keypoints: np.ndarray, pitch_deg: float, im_width: int, im_height: int, device: int = 0):
+    """spherical_surf::rotate_keypoint on cv::KeyPoint-like records (first two float32 = pt.x, pt.y); returns a copy."""
+    return _kp_inplace("sba_rotate_keypoints", keypoints, C.c_float(pitch_deg), im_width, im_height, device=device)
+
+
+def cube2equi_keypoints(keypoints: np.ndarray, cube_size: int, im_width: int, im_height: int, device: int = 0):
+    """equi2cube_surf::cube2equi_pixel on key-point records; returns a copy."""
+    return _kp_inplace("sba_cube2equi_keypoints", keypoints, cube_size, im_width, im_height, device=device)
+
+
+def crop_rotated_image(erp: np.ndarray, pitch_deg: float, device: int = 0) -> np.ndarray:
+    """spherical_surf::crop_rotated_image: (H, W, 3) uint8 -> (H//4, W, 3) rotated equatorial band."""
+    lib = cabi.load_library()
+    im = np.ascontiguousarray(erp, dtype=np.uint8)
+    if im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError("erp must be (H, W, 3) uint8")
+    out = np.zeros((im.shape[0] // 4, im.shape[1], 3), dtype=np.uint8)
+    cabi.check(lib, lib.sba_crop_rotated_image(device, im.ctypes.data_as(C.c_void_p), im.shape[0], im.shape[1],
+                                               C.c_float(pitch_deg), out.ctypes.data_as(C.c_void_p)))
+    return out

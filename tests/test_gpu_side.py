@@ -96,3 +96,42 @@ def test_set_depths(oracle):
         got2 = p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
         ref2 = oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=2 * c.d12)
         assert np.abs(got2.H - ref2.H).max() <= 1e-12 * np.abs(ref2.H).max()
+
+
+def test_matcher_coordinate_maps(oracle):
+    """rotate_keypoint / cube2equi_pixel / crop_rotated_image (spherical_surf.cpp:76-123, equi2cube_surf.cpp:19-76):
+    integer pixel results identical to the oracle, float ones to float rounding."""
+    rng = np.random.default_rng(21)
+    H, W, S, n = 1920, 3840, 600, 50001
+    kp = np.zeros((n, 7), dtype=np.float32)
+    kp[:, 0] = rng.uniform(0, W - 1, n); kp[:, 1] = rng.uniform(0, H // 4 - 1, n)
+    kp[:, 2:] = rng.standard_normal((n, 5))                       # size/angle/response/octave/class_id ride along untouched
+    # The bands of spherical_surf::do_all are +45, -45 and -90 (the 0 band only gets the offset added, .cpp:181-184).
+    # +-45: every integer band pixel maps identically.  -90: inputs on column 3W/4 or the equator row land EXACTLY on integer pixel
+    # boundaries (e.g. 2651.0 vs 2650.99..), where the truncation follows the last bit of sin/cos/acos/atan2 -- the
+    # reference's own value there depends on its libm build; those ties (0.008 % of the band) may differ by one pixel.
+    rows = np.arange(H // 4)
+    allkp = np.zeros((len(rows) * W, 7), dtype=np.float32)
+    rr, cc = np.meshgrid(rows, np.arange(W), indexing="ij")
+    allkp[:, 0], allkp[:, 1] = cc.ravel(), rr.ravel()
+    for pitch, allowed in ((45.0, 0.0), (-45.0, 0.0), (-90.0, 2e-4)):
+        for pts in (kp, allkp):
+            got = api.rotate_keypoints(pts, pitch, W, H)
+            ref = oracle.rotate_keypoints(pts, pitch, W, H)
+            assert np.array_equal(got[:, 2:], pts[:, 2:])
+            bad = (got[:, :2] != ref[:, :2]).any(axis=1)
+            assert bad.mean() <= allowed, f"pitch {pitch}: {int(bad.sum())} of {len(pts)} key-points differ"
+            assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1.0
+    cube = np.zeros((n, 7), dtype=np.float32)
+    cube[:, 0] = rng.uniform(0, 6 * S, n); cube[:, 1] = rng.uniform(0, S, n)
+    cube[:6, 0] = [S / 2 + k * S for k in range(6)]; cube[:6, 1] = S / 2
+    got = api.cube2equi_keypoints(cube, S, W, H)
+    ref = oracle.cube2equi_keypoints(cube, S, W, H)
+    assert np.abs(got[:, :2] - ref[:, :2]).max() <= 5e-4           # float32 pixels of a 3840-wide image: 1 ulp = 2.4e-4
+    im = rng.integers(0, 256, (480, 960, 3), dtype=np.uint8)
+    for pitch, allowed in ((45.0, 0.0), (-45.0, 0.0), (-90.0, 1e-3)):      # same pixel-boundary ties at -90 as above
+        got = api.crop_rotated_image(im, pitch)
+        ref = oracle.crop_rotated_image(im, pitch)
+        mism = (got != ref).any(axis=2).mean()
+        assert mism <= allowed, f"pitch {pitch}: {mism:.2e} of the pixels differ"
+    assert api.rotate_keypoints(kp[:0], 45.0, W, H).shape == (0, 7)

@@ -189,3 +189,34 @@ def test_depth_stage_oracle(oracle):
     # restart from the result: converges without moving
     d4, s4, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, d3)
     assert rc == 0 and s4.num_successful_steps <= 1 and np.abs(d4 - d3).max() < 1e-3
+
+
+def test_matcher_coordinate_maps_oracle(oracle):
+    """rotate_keypoint / crop_rotated_image / cube2equi_pixel restatements: consistency properties."""
+    H, W, S = 480, 960, 120
+    # pitch 0: rotate_keypoint only adds the band offset H*3/8 and truncates like Vec2i
+    kp = np.zeros((5, 7), dtype=np.float32)
+    kp[:, 0] = [0.0, 10.7, 500.2, 959.0, 333.3]
+    kp[:, 1] = [0.0, 5.5, 60.9, 119.0, 77.7]
+    out = oracle.rotate_keypoints(kp, 0.0, W, H)
+    assert np.abs(out[:, 0] - np.floor(kp[:, 0])).max() <= 1 and np.abs(out[:, 1] - np.floor(kp[:, 1] + H * 3 // 8)).max() <= 1
+    # crop at pitch 0 is (up to the truncation round trip) the plain equatorial band im(roi) of do_all (.cpp:131-139)
+    rng = np.random.default_rng(2)
+    im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    band = oracle.crop_rotated_image(im, 0.0)
+    assert band.shape == (H // 4, W, 3)
+    same = (band == im[H * 3 // 8: H * 3 // 8 + H // 4]).all(axis=2).mean()
+    assert same > 0.5            # the int truncation of acos/atan2 round trips shifts some pixels by one
+    # rotating a band key-point by +45 then looking the pixel up in the rotated crop is consistent with the warp
+    band45 = oracle.crop_rotated_image(im, 45.0)
+    kq = np.zeros((1, 7), dtype=np.float32); kq[0, 0], kq[0, 1] = 200.0, 30.0
+    back = oracle.rotate_keypoints(kq, 45.0, W, H)
+    assert (band45[30, 200] == im[int(back[0, 1]), int(back[0, 0])]).all()
+    # cube2equi_pixel: the centre of each cube face maps to the ERP pixel of that face's axis
+    centres = np.zeros((6, 7), dtype=np.float32)
+    centres[:, 0] = [S / 2 + k * S for k in range(6)]; centres[:, 1] = S / 2
+    e = oracle.cube2equi_keypoints(centres, S, W, H)
+    #            left(+y)   front(-x)  right(-y)   back(+x)  top(+z)   bottom(-z)
+    assert np.allclose(e[:4, 1], H / 2, atol=1e-3)
+    assert np.allclose(e[:4, 0], [W / 4, W / 2, 3 * W / 4, 0.0], atol=1e-3)
+    assert e[4, 1] < 1e-3 and abs(e[5, 1] - H) < 1e-3
