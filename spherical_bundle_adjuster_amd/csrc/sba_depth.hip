@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
   __shared__ double red[4][8];
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gmax = 0;
-  const double cl = P.c * P.lambda;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < P.n; i += stride) {
     const double x = static_cast<const ST*>(pl.x1[0])[i], y = static_cast<const ST*>(pl.x1[1])[i],
                  z = static_cast<const ST*>(pl.x1[2])[i];
@@ -86,7 +85,6 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
     const double f0 = nb * u - na * q0 + P.t[0], f1 = nb * v - na * q1 + P.t[1], f2 = nb * w - na * q2 + P.t[2];
     const double f4 = P.lambda * exp(-P.c * na), f5 = P.lambda * exp(-P.c * nb);
     cand_cost += 0.5 * (f0 * f0 + f1 * f1 + f2 * f2 + f4 * f4 + f5 * f5);
-    (void)cl;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double r[6] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),
