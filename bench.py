@@ -188,7 +188,7 @@ def main():
                                     f"{a.n} synthetic correspondences per GPU, {a.workload} sweep"),
                        "correspondences_per_gpu": a.n, "mode": a.workload, "storage": a.store,
                        "bytes_per_eval": bytes_per_eval, "allreduce": transport, "kernel": a.kernel,
-                       "step": "sweep kernel with fused final reduction + all-reduce(24 f64, N>1) + pack published to the host and awaited"},
+                       "step": "sweep kernel + finalize kernel + all-reduce(24 f64, N>1) + pack published to the host and awaited"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(kernel_sig, a.n),
                          "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "

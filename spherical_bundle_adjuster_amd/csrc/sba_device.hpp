@@ -58,7 +58,10 @@ struct SweepOut {
 hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& pl, const SweepParams& prm,
                         const SweepOut& out, int grid, hipStream_t stream);
 hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
-hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream);
+// Folds partials[nblocks][kRow] into pack_out[24]; with pack_host_dev != nullptr also publishes the pack to mapped
+// pinned host memory followed by `seq` at [24] for the host to poll.
+hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
+                           unsigned long long seq, hipStream_t stream);
 // pack_dev[24] -> mapped pinned host memory, then `seq` at pack_host[24] (64-bit) for the host to poll.
 hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,
                           hipStream_t stream);

@@ -516,7 +516,8 @@ __global__ __launch_bounds__(64) void batch_finalize_kernel(const double* __rest
 // blocks g, g+32, ... for its slot (4 independent chains so the loads pipeline), then the 32 groups are
 // summed serially per slot.  Independent of timing, so results are run-to-run identical.
 __global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict__ partials,
-                                                        int nblocks, double* __restrict__ pack_out) {
+                                                        int nblocks, double* __restrict__ pack_out,
+                                                        double* __restrict__ pack_host, unsigned long long seq) {
   __shared__ double part[32][33];
   const int slot = threadIdx.x & 31, grp = threadIdx.x >> 5;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -537,6 +538,14 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict
 #pragma unroll
     for (int g = 1; g < 32; ++g) tot += part[g][threadIdx.x];
     pack_out[threadIdx.x] = tot;
+    if (pack_host) pack_host[threadIdx.x] = tot;
+  }
+  if (pack_host && threadIdx.x < 64) {   // wave 0 stored the pack: system-scope release, then the polled sequence number
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), seq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -778,8 +787,9 @@ hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigne
   return hipGetLastError();
 }
 
-hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, hipStream_t stream) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out);
+hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
+                           unsigned long long seq, hipStream_t stream) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out, pack_host_dev, seq);
   return hipGetLastError();
 }
 

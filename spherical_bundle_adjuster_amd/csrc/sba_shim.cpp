@@ -148,7 +148,8 @@ struct sba_problem {
   double* pack_host_dev = nullptr;  // device-visible address of pack_host
   unsigned int* ticket = nullptr;   // arrival counter of the fused final reduction
   unsigned long long seq = 0;       // sweeps launched with host publication
-  bool fused = true;                // SBA_FUSED=0: two-kernel mode (sweep + finalize_kernel + D2H copy)
+  int fused_mode = 0;               // SBA_FUSED: 0 (default) never, 1 always, 2 only for grids <= kFusedMaxGrid
+  bool publish = true;              // SBA_PUBLISH=0: D2H copy + stream sync instead of kernel-side publication
   bool published = false;           // the last enqueued sweep publishes to pack_host itself
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_events;        // eval_timed: brackets of each sweep launch
@@ -253,20 +254,30 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   int grid = 0;
   int rc0 = grid_for(p, mode, depth_mode, prm.delta > 0.0, &grid);
   if (rc0) return rc0;
-  // Single-GPU: the sweep's last block publishes the pack to mapped host memory (no finalize kernel, no copy).
-  // With an all-reduce to follow, the fused reduction only fills pack_dev.
+  // Final reduction + hand-over.  Default: the sweep stays a pure streaming kernel and a one-block finalize kernel
+  // folds the block rows and publishes the pack into mapped pinned host memory, followed by a sequence number the
+  // host polls -- no blit kernel for a 192-byte D2H, no stream synchronisation.  Optional (SBA_FUSED=1/2): the
+  // sweep's last-arriving block does the fold and the publication itself; measured equal in step time at 10^7 and at
+  // 2 048 matches, but it lengthens the dominant kernel by ~5 us, so it is not the default.  With an all-reduce to
+  // follow, the pack stays on the device and publish_kernel hands it over afterwards.
+  constexpr int kFusedMaxGrid = 128;
   const bool collective = p->comm != nullptr || p->hook != nullptr;
+  const bool fused = grid > 0 && (p->fused_mode == 1 || (p->fused_mode == 2 && grid <= kFusedMaxGrid));
+  const bool to_host = p->publish && !collective;
   sba::SweepOut out;
   out.partials = p->partials;
   out.pack_dev = p->pack_dev;
-  out.ticket = p->fused ? p->ticket : nullptr;
-  p->published = p->fused && !collective && grid > 0;
-  out.pack_host = p->published ? p->pack_host_dev : nullptr;
-  out.seq = p->published ? ++p->seq : 0;
+  out.ticket = fused ? p->ticket : nullptr;
+  p->published = to_host;
+  if (to_host) ++p->seq;
+  out.pack_host = (fused && to_host) ? p->pack_host_dev : nullptr;
+  out.seq = p->seq;
   if (p->ev_sweep0) SBA_HIP_TRY(hipEventRecord(p->ev_sweep0, p->stream));
   SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, out, grid, p->stream));
   if (p->ev_sweep1) SBA_HIP_TRY(hipEventRecord(p->ev_sweep1, p->stream));
-  if (!p->fused || grid == 0) SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, p->stream));
+  if (!fused)
+    SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
+                                     p->stream));
   if (p->comm) {
     Rccl& r = rccl();
     const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
@@ -278,8 +289,8 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
     const int rc = p->hook(p->pack_dev, SBA_PACK_SIZE, p->stream, p->hook_user);
     if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
   }
-  if (collective && p->fused) {
-    // the all-reduced pack is published by a one-wave kernel (host polls), like the single-GPU sweep does itself
+  if (collective && p->publish) {
+    // the all-reduced pack is published by a one-wave kernel (host polls), like the single-GPU path does itself
     SBA_HIP_TRY(sba::launch_publish(p->pack_dev, p->pack_host_dev, ++p->seq, p->stream));
     p->published = true;
   }
@@ -380,7 +391,8 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   SBA_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->pack_host_dev), p->pack_host, 0));
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->ticket), 9 * 64));
   SBA_HIP_TRY(hipMemset(p->ticket, 0, 9 * 64));
-  if (const char* env = std::getenv("SBA_FUSED")) p->fused = std::strcmp(env, "0") != 0;
+  if (const char* env = std::getenv("SBA_FUSED")) p->fused_mode = std::atoi(env) == 0 ? 0 : (std::atoi(env) == 1 ? 1 : 2);
+  if (const char* env = std::getenv("SBA_PUBLISH")) p->publish = std::strcmp(env, "0") != 0;
   SBA_HIP_TRY(hipEventCreate(&p->ev0));
   SBA_HIP_TRY(hipEventCreate(&p->ev1));
   *out = p;

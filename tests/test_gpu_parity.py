@@ -257,12 +257,14 @@ def test_depth_stage_errors():
 
 
 def test_fused_and_two_kernel_reduction_agree(oracle, monkeypatch):
-    """SBA_FUSED=0 (sweep + finalize kernel + D2H copy) and the default fused last-block reduction with host
-    publication give the same pack (different but fixed fold orders: equal to rounding), each deterministic."""
+    """The in-kernel fused last-block reduction (SBA_FUSED=1), the sweep + publishing finalize kernel (SBA_FUSED=0)
+    and the legacy D2H copy (SBA_PUBLISH=0) give the same pack (different but fixed fold orders: equal to
+    rounding), each deterministic."""
     c = synthetic.full_rt(300007, seed=404)
     packs = {}
-    for fused in ("1", "0"):
+    for fused, publish in (("1", "1"), ("0", "1"), ("0", "0"), ("2", "1")):
         monkeypatch.setenv("SBA_FUSED", fused)
+        monkeypatch.setenv("SBA_PUBLISH", publish)
         with api.Problem(0) as p:
             p.upload(c.x1, c.x2, c.d12)
             a = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
@@ -270,7 +272,8 @@ def test_fused_and_two_kernel_reduction_agree(oracle, monkeypatch):
                 assert np.array_equal(a, p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH))
             b, _, _ = p.eval_timed(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, repeat=7)
             assert np.array_equal(a, b)
-            packs[fused] = a
-    assert np.abs(packs["1"] - packs["0"]).max() <= 1e-13 * np.abs(packs["0"]).max()
+            packs[fused + publish] = a
+    assert np.array_equal(packs["01"], packs["00"]) and np.array_equal(packs["01"], packs["21"])   # same kernels
+    assert np.abs(packs["11"] - packs["01"]).max() <= 1e-13 * np.abs(packs["01"]).max()
     ref = pack_from_eval(2, oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12))
-    assert np.abs(packs["1"] - ref).max() <= REL_TOL_F64 * np.abs(ref).max()
+    assert np.abs(packs["11"] - ref).max() <= REL_TOL_F64 * np.abs(ref).max()
