@@ -208,9 +208,10 @@ int sba_problem_eval_pack(sba_problem* p, int mode, int depth_mode, const double
                           double pack[SBA_PACK_SIZE]);
 
 /* Enqueue `repeat` back-to-back sweeps without host synchronisation in between and time them with
- * HIP events recorded on the problem's stream: *mean_step_ms = (sweep + finalize [+ all-reduce]) per
- * repeat, *mean_sweep_ms = the sweep kernel alone (events bracket each sweep launch).  Either output
- * pointer may be NULL.  The last sweep's pack is returned.  This is bench.py's timing primitive.  */
+ * HIP events recorded on the problem's stream: *mean_step_ms = (sweep + finalize [+ all-reduce] +
+ * publication) per repeat; *mean_sweep_ms = the sweep kernel alone, `repeat` launches back to back under
+ * one event pair (kernel + the boundary between dependent launches).  Either output pointer may be NULL.
+ * The last sweep's pack is returned.  This is bench.py's timing primitive.                          */
 int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const double rot[3],
                            const double tran[3], double d1, double d2, double huber_delta,
                            int repeat, double pack[SBA_PACK_SIZE], double* mean_step_ms,

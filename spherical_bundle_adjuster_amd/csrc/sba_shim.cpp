@@ -127,7 +127,9 @@ struct sba_problem {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cus = 0;
-  int blocks_per_cu_cap = 8;   // SBA_BLOCKS_PER_CU: upper bound on resident blocks per CU used
+  int blocks_per_cu_cap = 2;   // SBA_BLOCKS_PER_CU: resident blocks per CU used.  2 (8 waves/CU) measured best or tied
+                               // in every mode: the register double buffer supplies the memory-level parallelism,
+                               // more waves only add rows to fold (profiles/r01_tune_caps.log)
   int kind = SBA_KERNEL_FACTORED;
   int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
@@ -152,8 +154,6 @@ struct sba_problem {
   bool publish = true;              // SBA_PUBLISH=0: D2H copy + stream sync instead of kernel-side publication
   bool published = false;           // the last enqueued sweep publishes to pack_host itself
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<hipEvent_t> sweep_events;        // eval_timed: brackets of each sweep launch
-  hipEvent_t ev_sweep0 = nullptr, ev_sweep1 = nullptr;
 
   sba_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
@@ -272,9 +272,7 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   if (to_host) ++p->seq;
   out.pack_host = (fused && to_host) ? p->pack_host_dev : nullptr;
   out.seq = p->seq;
-  if (p->ev_sweep0) SBA_HIP_TRY(hipEventRecord(p->ev_sweep0, p->stream));
   SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, out, grid, p->stream));
-  if (p->ev_sweep1) SBA_HIP_TRY(hipEventRecord(p->ev_sweep1, p->stream));
   if (!fused)
     SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
                                      p->stream));
@@ -414,7 +412,6 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
-  for (hipEvent_t e : p->sweep_events) (void)hipEventDestroy(e);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return SBA_OK;
@@ -581,34 +578,38 @@ int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const doubl
   sba::SweepParams prm;
   make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);
   make_frame(p, mode, rot);
-  while (p->sweep_events.size() < static_cast<size_t>(2 * repeat)) {
-    hipEvent_t e;
-    SBA_HIP_TRY(hipEventCreate(&e));
-    p->sweep_events.push_back(e);
+  float ms = 0.f;
+  if (mean_sweep_ms) {
+    // the sweep kernel alone: `repeat` launches back to back under ONE event pair (kernel + the ~1.5 us boundary
+    // between dependent launches; per-launch event brackets would add another 2-4 us each)
+    int grid = 0;
+    rc = grid_for(p, mode, depth_mode, prm.delta > 0.0, &grid);
+    if (rc) return rc;
+    sba::Planes pl;
+    for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+    pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+    sba::SweepOut out;
+    out.partials = p->partials; out.pack_dev = p->pack_dev; out.pack_host = nullptr; out.ticket = nullptr; out.seq = 0;
+    SBA_HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    for (int i = 0; i < repeat; ++i)
+      SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, out, grid, p->stream));
+    SBA_HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    SBA_HIP_TRY(hipEventSynchronize(p->ev1));
+    SBA_HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    *mean_sweep_ms = static_cast<double>(ms) / repeat;
   }
+  // complete steps (sweep + final reduction [+ all-reduce] + publication), still without host synchronisation between them
   SBA_HIP_TRY(hipEventRecord(p->ev0, p->stream));
   for (int i = 0; i < repeat; ++i) {
-    p->ev_sweep0 = p->sweep_events[2 * i];
-    p->ev_sweep1 = p->sweep_events[2 * i + 1];
     rc = enqueue_sweep(p, mode, depth_mode, prm);
-    p->ev_sweep0 = p->ev_sweep1 = nullptr;
     if (rc) return rc;
   }
   SBA_HIP_TRY(hipEventRecord(p->ev1, p->stream));
   rc = fetch_pack(p, pack);
   if (rc) return rc;
   SBA_HIP_TRY(hipEventSynchronize(p->ev1));
-  float ms = 0.f;
   SBA_HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   if (mean_step_ms) *mean_step_ms = static_cast<double>(ms) / repeat;
-  if (mean_sweep_ms) {
-    double tot = 0.0;
-    for (int i = 0; i < repeat; ++i) {
-      SBA_HIP_TRY(hipEventElapsedTime(&ms, p->sweep_events[2 * i], p->sweep_events[2 * i + 1]));
-      tot += ms;
-    }
-    *mean_sweep_ms = tot / repeat;
-  }
   return SBA_OK;
 }
 
