@@ -19,7 +19,13 @@
  *   - pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
  *       -> sba_keypoints_to_sphere()
  *   - equi2cube::get_all (equi2cube.cpp:12-302)
- *       -> sba_equi2cube()
+ *       -> sba_equi2cube(), sba_equi2cube_device()
+ *   - initial_guess / eight_point_estimation (spherical_bundle_adjuster.cpp:47-181)
+ *       -> sba_problem_initial_guess()
+ *   - spherical_surf::rotate_keypoint / crop_rotated_image, equi2cube_surf::cube2equi_pixel
+ *       -> sba_rotate_keypoints(), sba_crop_rotated_image(), sba_cube2equi_keypoints()
+ *   - one run of main/main.cpp per image pair
+ *       -> sba_batch_*()                   (many pairs per launch, one LM per pair)
  *
  * Conventions
  *   - every function returns an int status: 0 = SBA_OK, negative = error; the text of the
