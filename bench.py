@@ -139,7 +139,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream if use_hook else None
     p = api.Problem(local_rank, stream=stream)
     p.set_kernel(api.KERNEL_EXPLICIT if a.kernel == "explicit" else api.KERNEL_FACTORED)
-    p.upload(c.x1, c.x2, c.d12 if rt else None, store=store)
+    t_up = time.perf_counter()
+    p.upload(c.x1, c.x2, c.d12 if rt else None, store=store)      # host cv::Point3d-layout arrays -> device planes
+    upload_s = time.perf_counter() - t_up
     transport = "none"
     if world > 1:
         transport = distributed.attach(p, prefer_native=a.transport != "hook")
@@ -201,6 +203,8 @@ def main():
                    "iterations": summ.num_iterations, "termination": summ.termination,
                    "rot_err_rad": float(np.abs(r_s - c.rot_true).max()),
                    "tran_err": float(np.abs(t_s - c.tran_true).max())},
+            "upload_s": upload_s,   # once per problem (H2D over PCIe + re-layout); never part of `value`
+            "pcie_inclusive_evals_per_s_if_reuploaded_every_sweep": a.n / (upload_s + elapsed / a.steps),
             "cost": float(pack[22]),
         }
         if not a.no_cpu_baseline and world == 1:
