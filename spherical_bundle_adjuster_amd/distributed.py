@@ -20,14 +20,15 @@ class _DevicePack:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
-def attach(problem: api.Problem, prefer_native: bool = True) -> str:
+def attach(problem: api.Problem, prefer_native: bool = True, force: bool = False) -> str:
     """Install the per-sweep all-reduce on `problem` for the current torch.distributed world.
-    Returns the transport used: "none" (world size 1), "rccl-native" or "torch-hook"."""
+    Returns the transport used: "none" (world size 1, unless `force`), "rccl-native" or "torch-hook".
+    The torch-hook transport requires the problem to have been created on torch's current stream."""
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
-    if world == 1:
+    if world == 1 and not force:
         return "none"
     dev = torch.device("cuda", torch.cuda.current_device())
     if prefer_native:

@@ -135,3 +135,44 @@ def test_matcher_coordinate_maps(oracle):
         mism = (got != ref).any(axis=2).mean()
         assert mism <= allowed, f"pitch {pitch}: {mism:.2e} of the pixels differ"
     assert api.rotate_keypoints(kp[:0], 45.0, W, H).shape == (0, 7)
+
+
+def test_distributed_attach_one_rank_process_group(oracle):
+    """distributed.attach() on a 1-rank NCCL(=RCCL) process group: the native transport (unique id shipped through
+    torch.distributed, ncclCommInitRank inside the shim) and the torch hook (all_reduce on a tensor aliasing the
+    shim's device pack) must both leave single-rank results unchanged and keep the LM working."""
+    import os
+    import socket
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from spherical_bundle_adjuster_amd import distributed
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = synthetic.full_rt(20000, seed=31)
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, c.d12)
+            base = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            assert distributed.attach(p) == "none"
+            assert distributed.attach(p, prefer_native=True, force=True) == "rccl-native"
+            assert np.array_equal(p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH), base)
+            r, t, s_ = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            assert s_.termination.startswith("CONVERGENCE")
+        with api.Problem(0, stream=torch.cuda.current_stream().cuda_stream) as p:
+            p.upload(c.x1, c.x2, c.d12)
+            assert distributed.attach(p, prefer_native=False, force=True) == "torch-hook"
+            got = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            assert np.array_equal(got, base)
+            # the alias really is the shim's device pack: explicit kernel -> device pack == SBA pack layout
+            p.set_kernel(api.KERNEL_EXPLICIT)
+            got = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            torch.cuda.synchronize()
+            assert np.array_equal(p._torch_pack_alias.cpu().numpy(), got)
+            r2, t2, s2 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            assert np.abs(r2 - r).max() <= 1e-12 and s2.num_iterations == s_.num_iterations
+    finally:
+        dist.destroy_process_group()
