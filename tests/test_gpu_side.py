@@ -176,3 +176,21 @@ def test_distributed_attach_one_rank_process_group(oracle):
             assert np.abs(r2 - r).max() <= 1e-12 and s2.num_iterations == s_.num_iterations
     finally:
         dist.destroy_process_group()
+
+
+def test_upload_from_device_arrays(oracle):
+    """sba_problem_upload_device: cv::Point3d-layout arrays already resident on the GPU (here torch tensors)."""
+    torch = pytest.importorskip("torch")
+    c = synthetic.full_rt(30001, seed=55)
+    x1 = torch.from_numpy(c.x1).cuda(); x2 = torch.from_numpy(c.x2).cuda(); d12 = torch.from_numpy(c.d12).cuda()
+    torch.cuda.synchronize()
+    ref = oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12)
+    with api.Problem(0) as p:
+        p.upload_device(x1.data_ptr(), x2.data_ptr(), d12.data_ptr(), 30001)
+        got = p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        assert np.abs(got.H - ref.H).max() <= 1e-12 * np.abs(ref.H).max() and got.n_outlier == ref.n_outlier
+        p.upload_device(x1.data_ptr(), x2.data_ptr(), None, 30001, store=api.STORE_F32)     # no depths, f32 planes
+        got = p.eval(api.MODE_ROT, c.rot_init, c.tran_init, 1.2, 0.8)
+        ref2 = oracle.evaluate(0, c.x1.astype(np.float32).astype(np.float64), c.x2.astype(np.float32).astype(np.float64),
+                               c.rot_init, c.tran_init, 1.2, 0.8)
+        assert np.abs(got.H - ref2.H).max() <= 1e-12 * np.abs(ref2.H).max()
