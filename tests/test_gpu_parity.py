@@ -277,3 +277,33 @@ def test_fused_and_two_kernel_reduction_agree(oracle, monkeypatch):
     assert np.abs(packs["11"] - packs["01"]).max() <= 1e-13 * np.abs(packs["01"]).max()
     ref = pack_from_eval(2, oracle.evaluate(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12))
     assert np.abs(packs["11"] - ref).max() <= REL_TOL_F64 * np.abs(ref).max()
+
+
+# ---- degenerate inputs -----------------------------------------------------------------------------------
+def test_degenerate_inputs_fail_loudly_or_terminate_sanely(oracle):
+    with api.Problem(0) as p:
+        # NaN in the data: the sweep returns a non-finite cost and the solve refuses it (no silent garbage)
+        c = synthetic.rotation_only(1000, seed=3)
+        bad = c.x1.copy(); bad[17, 1] = np.nan
+        p.upload(bad, c.x2)
+        assert not np.isfinite(p.eval(api.MODE_ROT, c.rot_init, c.tran_init).cost)
+        with pytest.raises(api.SbaError) as ei:
+            p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
+        assert ei.value.code == -6
+        # rank-deficient geometry: every match is the same point -> rotation about that axis is unobservable.
+        # The damped system stays positive definite; the solve must end in a finite state, like the oracle's.
+        x = np.tile(np.array([[0.0, 0.6, 0.8]]), (500, 1))
+        p.upload(x, x)
+        r, t, s = p.solve(api.MODE_ROT, [0.01, 0.02, -0.01], [0, 0, 0])
+        ro, to, so, rc = oracle.lm_solve(0, x, x, [0.01, 0.02, -0.01], [0, 0, 0])
+        assert rc == 0 and np.isfinite(r).all() and s.termination != "FAILURE"
+        assert np.abs(r - ro).max() < 1e-9 and s.num_iterations == so.num_iterations
+        # a rotation of nearly pi: the start point sits where sin(theta)/theta is small but well conditioned
+        c = synthetic.rotation_only(5000, seed=8, sigma=0.0, outlier_fraction=0.0)
+        axis = c.rot_true / np.linalg.norm(c.rot_true)
+        big = axis * 3.0
+        x2 = c.x1 @ synthetic.rodrigues(big).T
+        p.upload(c.x1, x2)
+        r, t, s = p.solve(api.MODE_ROT, big + 0.02, [0, 0, 0], options=api.default_lm_options(huber_delta=0.0,
+                          function_tolerance=1e-30, parameter_tolerance=1e-14, gradient_tolerance=1e-16))
+        assert np.abs(r - big).max() < 1e-9
