@@ -9,9 +9,9 @@ C3, "10M synthetic correspondences, full R|t (5-DoF) LM BA, 1xMI355X" -- 10^7 un
 correspondences with per-match depths (64 algorithmic bytes per evaluation: 2 x 3 f64 unit-vector
 components + 2 f64 depths), f64 arithmetic.  A *step* is one pass of the hot path over the resident
 correspondences exactly as one LM iteration needs it: sweep kernel (residual + analytic Jacobian +
-Huber + reduction), finalize kernel, one all-reduce of the 24-double pack when N > 1, 192-byte D2H and
-host synchronisation.  Weak scaling: every rank holds 10^7 correspondences of the same two-view
-geometry, no data-path collective other than that all-reduce.
+Huber + reduction), finalize kernel, one exchange (all-reduce) of the 24-double pack when N > 1, and the pack
+published to and awaited by the host.  Weak scaling: every rank holds 10^7 correspondences of the same two-view
+geometry, no data-path communication other than that one exchange per step.
 
 One JSON line on rank 0.  `roofline` prices the sweep kernel alone against HBM (device time from HIP
 events recorded around each sweep launch on the problem's stream); `cpu_baseline` times the oracle's
@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--transport", choices=["auto", "native", "hook"], default="auto")
+    ap.add_argument("--transport", choices=["auto", "peer", "rccl", "hook"], default="auto",
+                    help="N > 1: exchange of the 24-double pack per step (auto = peer if its self-test passes on every "
+                         "rank, else RCCL all-reduce, else torch.distributed hook)")
     ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
     return ap.parse_args()
 
@@ -144,7 +146,7 @@ def main():
     upload_s = time.perf_counter() - t_up
     transport = "none"
     if world > 1:
-        transport = distributed.attach(p, prefer_native=a.transport != "hook")
+        transport = distributed.attach(p, transport=a.transport)
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,6 +157,7 @@ def main():
     rot, tran = c.rot_init.copy(), c.tran_init.copy()
     # W warm-up steps, then EXACTLY K steps, each host-synchronous (launch -> reduction -> all-reduce -> result on
     # the host) and driven from C++ like the LM loop drives them (sba_problem_eval_steps), bracketed by barriers.
+    barrier()   # ranks generate and upload their shards at different speeds: enter the first exchange together
     if a.warmup > 0:
         p.eval_steps(mode, rot, tran, depth_mode=depth_mode, steps=a.warmup)
     barrier()

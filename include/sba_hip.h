@@ -256,6 +256,18 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
 #define SBA_COMM_ID_BYTES 128
 int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]);
 int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]);
+/* Option C: direct peer exchange, no collective library on the data path.  Every rank owns a 4 KiB inbox in
+ * fine-grained device memory that all peers map through HIP IPC; per sweep one wave stores its 24 doubles into every
+ * peer's inbox (over xGMI), polls its own inbox and sums the nranks contributions in rank order (bit-identical on all
+ * ranks), then publishes to the host.  Set-up: every rank calls sba_problem_peer_export (allocates the inbox, returns
+ * its 64-byte IPC handle), the handles are all-gathered by any host channel into handles[nranks][64], every rank calls
+ * sba_problem_peer_connect, then all ranks together sba_problem_peer_selftest; on any failure call
+ * sba_problem_peer_disable everywhere and use option A.  At most 8 ranks (one node).                            */
+#define SBA_PEER_HANDLE_BYTES 64
+int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SBA_PEER_HANDLE_BYTES]);
+int sba_problem_peer_connect(sba_problem* p, const char* handles);
+int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok);
+int sba_problem_peer_disable(sba_problem* p);
 /* Option B: user hook (e.g. torch.distributed.all_reduce on a tensor aliasing device_buf).  */
 int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
 /* Device address of the 24-double result pack the hook / RCCL operates on (a sum over

@@ -24,6 +24,7 @@ TRAN_FREE, TRAN_SPHERE = 0, 1
 KERNEL_FACTORED, KERNEL_EXPLICIT = 0, 1
 PACK_SIZE = 24
 COMM_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
 TERMINATION = {1: "CONVERGENCE_FUNCTION", 2: "CONVERGENCE_GRADIENT", 3: "CONVERGENCE_PARAMETER",
                4: "NO_CONVERGENCE", 5: "MIN_RADIUS", 6: "FAILURE"}
 
@@ -106,6 +107,10 @@ SIGNATURES = {
     "sba_problem_initial_guess": (C.c_int, [_vp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp, C.POINTER(C.c_int)]),
     "sba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sba_problem_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
+    "sba_problem_peer_export": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
+    "sba_problem_peer_connect": (C.c_int, [_vp, C.c_char_p]),
+    "sba_problem_peer_selftest": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "sba_problem_peer_disable": (C.c_int, [_vp]),
     "sba_problem_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "sba_problem_pack_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "sba_batch_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),

@@ -231,6 +231,24 @@ class Problem:
             raise ValueError("unique_id must be 128 bytes")
         cabi.check(self._lib, self._lib.sba_problem_comm_init_rank(self._h, nranks, rank, unique_id))
 
+    def peer_export(self, nranks: int, rank: int) -> bytes:
+        """Allocate this rank's inbox for the direct peer exchange; returns its 64-byte IPC handle."""
+        buf = C.create_string_buffer(cabi.PEER_HANDLE_BYTES)
+        cabi.check(self._lib, self._lib.sba_problem_peer_export(self._h, nranks, rank, buf))
+        return buf.raw
+
+    def peer_connect(self, handles: bytes) -> None:
+        """handles: the nranks 64-byte IPC handles in rank order, concatenated."""
+        cabi.check(self._lib, self._lib.sba_problem_peer_connect(self._h, handles))
+
+    def peer_selftest(self, rounds: int = 8) -> bool:
+        ok = C.c_int(0)
+        cabi.check(self._lib, self._lib.sba_problem_peer_selftest(self._h, rounds, C.byref(ok)))
+        return bool(ok.value)
+
+    def peer_disable(self) -> None:
+        cabi.check(self._lib, self._lib.sba_problem_peer_disable(self._h))
+
     def set_allreduce(self, fn) -> None:
         """fn(device_ptr: int, count: int, stream: int) -> int (0 = ok), or None to clear."""
         if fn is None:

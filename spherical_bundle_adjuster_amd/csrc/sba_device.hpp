@@ -62,6 +62,18 @@ hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool lo
 // pinned host memory followed by `seq` at [24] for the host to poll.
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
                            unsigned long long seq, hipStream_t stream);
+// Direct peer exchange (all-reduce of the pack over IPC-mapped inboxes, see peer_exchange_kernel).
+constexpr int kMaxPeers = 8;
+constexpr size_t kInboxDoubles = 2 * kMaxPeers * 32;   // [parity][source rank][32] = 4 KiB per rank
+struct PeerInboxes {
+  double* inbox[kMaxPeers];   // device-visible address of every rank's inbox (index = rank, own included)
+  int nranks;
+  int rank;
+};
+hipError_t launch_peer_exchange(const double* pack_local, const PeerInboxes& px, unsigned long long xseq,
+                                double* pack_out, double* pack_host_dev, unsigned long long host_seq,
+                                unsigned long long spin_limit, hipStream_t stream);
+
 // pack_dev[24] -> mapped pinned host memory, then `seq` at pack_host[24] (64-bit) for the host to poll.
 hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,
                           hipStream_t stream);

@@ -561,6 +561,72 @@ __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ 
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- direct peer exchange over xGMI: the all-reduce of the 24-double pack without a collective library ----------
+// Every rank owns an "inbox" in fine-grained device memory, mapped into all peers through HIP IPC:
+//     inbox[parity][source rank][32]   (24 doubles of payload, word 31 = sequence number; 256 B per slot)
+// One wave per rank: (1) store the local pack into slot [parity][my rank] of EVERY rank's inbox (peer stores travel
+// over xGMI), (2) system-scope release, (3) store the sequence number into each of those slots, (4) poll the own
+// inbox until all nranks slots carry this sequence number, (5) system-scope acquire, (6) sum the slots in RANK ORDER
+// -- every rank adds the same numbers in the same order, so all ranks obtain the bit-identical result -- and
+// (7) publish the pack to the host like publish_kernel.  Two parities: a rank can run at most one exchange ahead of
+// the slowest (it needs everybody's slot of round s before it can finish round s), so round s+1 never overwrites a
+// slot somebody still reads.  Spins are bounded; on a timeout word 25 of the host pack is set so the host reports
+// SBA_ERR_COMM instead of waiting forever.
+__global__ __launch_bounds__(64) void peer_exchange_kernel(const double* __restrict__ pack_local, PeerInboxes px,
+                                                           unsigned long long seq, double* __restrict__ pack_out,
+                                                           double* __restrict__ pack_host,
+                                                           unsigned long long host_seq,
+                                                           unsigned long long spin_limit) {
+  const int lane = threadIdx.x;
+  const unsigned parity = static_cast<unsigned>(seq & 1ull);
+  const size_t my_slot = (static_cast<size_t>(parity) * kMaxPeers + px.rank) * 32;
+  // (1) payload to every inbox (own included): lanes 0..23 hold one double each
+  if (lane < 24) {
+    const double v = pack_local[lane];
+    for (int r = 0; r < px.nranks; ++r)
+      __hip_atomic_store(px.inbox[r] + my_slot + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // (2) + (3): all payload stores of this wave are complete and visible before any sequence number is
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < px.nranks)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(px.inbox[lane] + my_slot + 31), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  // (4) lane r waits for source rank r
+  bool ok = true;
+  if (lane < px.nranks) {
+    const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(
+        px.inbox[px.rank] + (static_cast<size_t>(parity) * kMaxPeers + lane) * 32 + 31);
+    unsigned long long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if (++spins > spin_limit) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  const bool all_ok = __ballot(!ok) == 0ull;
+  // (5)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  // (6)
+  if (lane < 24) {
+    double tot = 0.0;
+    for (int r = 0; r < px.nranks; ++r)
+      tot += __hip_atomic_load(px.inbox[px.rank] + (static_cast<size_t>(parity) * kMaxPeers + r) * 32 + lane,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    pack_out[lane] = tot;
+    if (pack_host) pack_host[lane] = tot;
+  }
+  // (7)
+  if (pack_host) {
+    if (lane == 0)
+      reinterpret_cast<unsigned long long*>(pack_host)[25] = all_ok ? 0ull : 1ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), host_seq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- layout conversion at upload time (once per problem, not per LM iteration) ---------------
 template <typename ST>
 __global__ void aos_to_planes_kernel(const double* __restrict__ aos, size_t n, size_t first,
@@ -784,6 +850,14 @@ hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& 
 hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,
                           hipStream_t stream) {
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, stream, pack_dev, pack_host_dev, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_peer_exchange(const double* pack_local, const PeerInboxes& px, unsigned long long xseq,
+                                double* pack_out, double* pack_host_dev, unsigned long long host_seq,
+                                unsigned long long spin_limit, hipStream_t stream) {
+  hipLaunchKernelGGL(peer_exchange_kernel, dim3(1), dim3(64), 0, stream, pack_local, px, xseq, pack_out, pack_host_dev,
+                     host_seq, spin_limit);
   return hipGetLastError();
 }
 

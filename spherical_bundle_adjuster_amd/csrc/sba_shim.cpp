@@ -155,6 +155,14 @@ struct sba_problem {
   bool published = false;           // the last enqueued sweep publishes to pack_host itself
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
+  // direct peer exchange (IPC-mapped inboxes, sba_problem_peer_*)
+  double* inbox = nullptr;
+  sba::PeerInboxes peers{};
+  void* peer_opened[sba::kMaxPeers] = {nullptr};
+  bool peer_ready = false;
+  unsigned long long xseq = 0;
+  unsigned long long peer_spin_limit = 20000000ull;   // bounded wait (tens of seconds) before SBA_ERR_COMM
+
   sba_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
   void* comm = nullptr;        // ncclComm_t
@@ -261,7 +269,7 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   // 2 048 matches, but it lengthens the dominant kernel by ~5 us, so it is not the default.  With an all-reduce to
   // follow, the pack stays on the device and publish_kernel hands it over afterwards.
   constexpr int kFusedMaxGrid = 128;
-  const bool collective = p->comm != nullptr || p->hook != nullptr;
+  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
   const bool fused = grid > 0 && (p->fused_mode == 1 || (p->fused_mode == 2 && grid <= kFusedMaxGrid));
   const bool to_host = p->publish && !collective;
   sba::SweepOut out;
@@ -276,6 +284,13 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   if (!fused)
     SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
                                      p->stream));
+  if (p->peer_ready) {
+    // all-reduce by direct peer stores over xGMI + rank-ordered local sum; the same wave publishes to the host
+    if (p->publish) { ++p->seq; p->published = true; }
+    SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev,
+                                          p->publish ? p->pack_host_dev : nullptr, p->seq, p->peer_spin_limit, p->stream));
+    return SBA_OK;
+  }
   if (p->comm) {
     Rccl& r = rccl();
     const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
@@ -296,7 +311,7 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
 }
 
 // Wait for the reduced pack on the host; the factored kernel's moments are mapped to the SBA_PACK_* layout.
-int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
+int fetch_pack_raw(sba_problem* p, double raw[SBA_PACK_SIZE]) {
   if (p->published) {
     // The kernel stores the 24 doubles, fences at system scope, then stores the sequence number: poll it.
     // A stream query every so often turns a device fault into an error instead of an endless spin.
@@ -312,15 +327,26 @@ int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
       __builtin_ia32_pause();
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
+      return fail(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's pack");
   } else {
     SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, p->pack_dev, SBA_PACK_SIZE * sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
     SBA_HIP_TRY(hipStreamSynchronize(p->stream));
   }
+  std::memcpy(raw, p->pack_host, SBA_PACK_SIZE * sizeof(double));
+  return SBA_OK;
+}
+
+// ... and map the factored kernel's moments to the SBA_PACK_* layout.
+int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
+  double raw[SBA_PACK_SIZE];
+  const int rc = fetch_pack_raw(p, raw);
+  if (rc) return rc;
   if (p->kind == SBA_KERNEL_FACTORED && p->last_mode != SBA_MODE_TRAN)
-    sba::moments_to_normal_pack(true, p->last_mode == SBA_MODE_RT, p->frame_B, p->frame_J, p->pack_host, pack);
+    sba::moments_to_normal_pack(true, p->last_mode == SBA_MODE_RT, p->frame_B, p->frame_J, raw, pack);
   else
-    std::memcpy(pack, p->pack_host, SBA_PACK_SIZE * sizeof(double));
+    std::memcpy(pack, raw, SBA_PACK_SIZE * sizeof(double));
   return SBA_OK;
 }
 
@@ -405,6 +431,7 @@ int sba_problem_destroy(sba_problem* p) {
     Rccl& r = rccl();
     if (r.ok) r.CommDestroy(p->comm);
   }
+  (void)sba_problem_peer_disable(p);
   free_planes(p);
   if (p->partials) (void)hipFree(p->partials);
   if (p->pack_dev) (void)hipFree(p->pack_dev);
@@ -663,6 +690,107 @@ int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char 
   if (p->comm) r.CommDestroy(p->comm);
   p->comm = comm;
   p->nranks = nranks;
+  return SBA_OK;
+}
+
+// ---- direct peer exchange ---------------------------------------------------------------------------------------
+int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SBA_PEER_HANDLE_BYTES]) {
+  if (!p || !handle) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (nranks < 1 || nranks > sba::kMaxPeers || rank < 0 || rank >= nranks)
+    return fail(SBA_ERR_INVALID_ARG, "bad rank %d/%d (at most %d ranks)", rank, nranks, sba::kMaxPeers);
+  static_assert(sizeof(hipIpcMemHandle_t) == SBA_PEER_HANDLE_BYTES, "IPC handle size");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  (void)sba_problem_peer_disable(p);
+  const size_t bytes = sba::kInboxDoubles * sizeof(double);
+  // fine-grained / uncached device memory: remote stores and local polls must not sit in a non-coherent cache
+  void* mem = nullptr;
+  if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      SBA_HIP_TRY(hipMalloc(&mem, bytes));
+    }
+  }
+  p->inbox = static_cast<double*>(mem);
+  SBA_HIP_TRY(hipMemset(p->inbox, 0, bytes));
+  SBA_HIP_TRY(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, p->inbox);
+  if (e != hipSuccess) {
+    (void)hipFree(p->inbox);
+    p->inbox = nullptr;
+    return fail(SBA_ERR_COMM, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
+  }
+  std::memcpy(handle, &h, SBA_PEER_HANDLE_BYTES);
+  p->peers.nranks = nranks;
+  p->peers.rank = rank;
+  return SBA_OK;
+}
+
+int sba_problem_peer_connect(sba_problem* p, const char* handles) {
+  if (!p || !handles) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  if (!p->inbox) return fail(SBA_ERR_INVALID_ARG, "call sba_problem_peer_export first");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  for (int r = 0; r < p->peers.nranks; ++r) {
+    if (r == p->peers.rank) { p->peers.inbox[r] = p->inbox; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + static_cast<size_t>(r) * SBA_PEER_HANDLE_BYTES, SBA_PEER_HANDLE_BYTES);
+    void* ptr = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)sba_problem_peer_disable(p);
+      return fail(SBA_ERR_COMM, "hipIpcOpenMemHandle(rank %d) failed: %s", r, hipGetErrorString(e));
+    }
+    p->peer_opened[r] = ptr;
+    p->peers.inbox[r] = static_cast<double*>(ptr);
+  }
+  p->xseq = 0;
+  p->peer_ready = true;
+  return SBA_OK;
+}
+
+int sba_problem_peer_disable(sba_problem* p) {
+  if (!p) return SBA_OK;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  for (auto& o : p->peer_opened) {
+    if (o) (void)hipIpcCloseMemHandle(o);
+    o = nullptr;
+  }
+  if (p->inbox) (void)hipFree(p->inbox);
+  p->inbox = nullptr;
+  p->peer_ready = false;
+  return SBA_OK;
+}
+
+// `rounds` exchanges of a known pack (rank + 1 in every slot, plus the round number): every rank must obtain
+// nranks (nranks + 1) / 2 + nranks * round.  *ok = 1 on success.  All ranks must call it together.
+int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok) {
+  if (!p || !ok) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  *ok = 0;
+  if (!p->peer_ready) return fail(SBA_ERR_INVALID_ARG, "peer exchange is not connected");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  const int n = p->peers.nranks;
+  const unsigned long long limit = p->peer_spin_limit;
+  p->peer_spin_limit = 3000000ull;   // a few seconds at most per round in the self-test
+  int good = 1;
+  for (int k = 0; k < rounds && good; ++k) {
+    double v[32];
+    for (int i = 0; i < 32; ++i) v[i] = static_cast<double>(p->peers.rank + 1 + k);
+    SBA_HIP_TRY(hipMemcpyAsync(p->pack_dev, v, 24 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    ++p->seq;
+    p->published = true;
+    SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev, p->pack_host_dev, p->seq,
+                                          p->peer_spin_limit, p->stream));
+    double got[24];
+    const int rc = fetch_pack_raw(p, got);
+    if (rc != SBA_OK) { good = 0; break; }
+    const double want = 0.5 * n * (n + 1) + static_cast<double>(n) * k;
+    for (int i = 0; i < 24; ++i)
+      if (got[i] != want) good = 0;
+  }
+  p->peer_spin_limit = limit;
+  *ok = good;
   return SBA_OK;
 }
 

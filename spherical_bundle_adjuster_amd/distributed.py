@@ -1,14 +1,22 @@
 """Multi-GPU glue: one process (and one ``Problem``) per GPU, correspondences sharded contiguously,
-ONE all-reduce of the 24-double normal-equation pack per sweep.
+ONE exchange of the 24-double normal-equation pack per sweep.  The payload is 192 bytes,
+so the exchange is latency-bound; xGMI bandwidth is irrelevant, the number of launches and hops is what counts.
 
-Two transports for that all-reduce:
-  * native  -- the C++ shim calls ``ncclAllReduce`` (RCCL) itself on the problem's stream; the
-               128-byte unique id is shipped between ranks with ``torch.distributed`` (host plumbing).
-  * hook    -- ``torch.distributed.all_reduce`` on a tensor aliasing the shim's device pack (needs
-               the problem to launch on torch's current stream).
-The payload is 192 bytes, so either way the exchange is latency-bound; xGMI bandwidth is irrelevant.
+Transports for that exchange (``attach(..., transport=...)``):
+  * "peer"   -- direct peer exchange: every rank's 4 KiB inbox is mapped into all peers with HIP IPC; one wave per
+                rank stores its pack into every inbox over xGMI, polls its own and sums in rank order (bit-identical on
+                all ranks), then publishes to the host.  No collective library on the data path.
+  * "rccl"   -- the C++ shim calls ``ncclAllReduce`` (RCCL) itself on the problem's stream; the 128-byte unique id is
+                shipped between ranks with ``torch.distributed``.
+  * "hook"   -- ``torch.distributed.all_reduce`` on a tensor aliasing the shim's device pack (needs the problem to
+                launch on torch's current stream).
+  * "auto"   -- "peer" if its set-up and an 8-round self-test succeed on EVERY rank, else "rccl", else "hook".
+``torch.distributed`` is host plumbing here (shipping handles / ids, agreeing on the fallback), never the data path
+of "peer" and "rccl".
 """
 from __future__ import annotations
+
+import os
 
 from . import api
 
@@ -20,30 +28,91 @@ class _DevicePack:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
-def attach(problem: api.Problem, prefer_native: bool = True, force: bool = False) -> str:
-    """Install the per-sweep all-reduce on `problem` for the current torch.distributed world.
-    Returns the transport used: "none" (world size 1, unless `force`), "rccl-native" or "torch-hook".
-    The torch-hook transport requires the problem to have been created on torch's current stream."""
+def _ctrl_device(torch, dist):
+    """Device for the few control messages: the process group's own (cuda for nccl, cpu for gloo)."""
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _all_agree(torch, dist, ok: bool) -> bool:
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_ctrl_device(torch, dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()) == 1)
+
+
+def _try_peer(problem: api.Problem, torch, dist) -> bool:
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _ctrl_device(torch, dist)
+    handle, ok = bytes(64), world <= 8
+    if ok:
+        try:
+            handle = problem.peer_export(world, rank)
+        except api.SbaError:
+            ok = False
+    mine = torch.tensor(list(handle), dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    if _all_agree(torch, dist, ok):
+        try:
+            problem.peer_connect(b"".join(bytes(g.cpu().tolist()) for g in gathered))
+        except api.SbaError:
+            ok = False
+    else:
+        ok = False
+    if _all_agree(torch, dist, ok):
+        try:
+            ok = problem.peer_selftest(8)
+        except api.SbaError:
+            ok = False
+    else:
+        ok = False
+    if _all_agree(torch, dist, ok):
+        return True
+    problem.peer_disable()
+    return False
+
+
+def _try_rccl(problem: api.Problem, torch, dist) -> bool:
+    world, rank = dist.get_world_size(), dist.get_rank()
+    uid, ok = bytes(128), 1
+    if rank == 0:
+        try:
+            uid = api.comm_unique_id()
+        except api.SbaError:
+            ok = 0
+    t = torch.tensor([ok] + list(uid), dtype=torch.int32, device=_ctrl_device(torch, dist))
+    dist.broadcast(t, 0)
+    vals = t.cpu().tolist()
+    if vals[0] != 1:
+        return False
+    problem.comm_init_rank(world, rank, bytes(vals[1:]))
+    return True
+
+
+def attach(problem: api.Problem, transport: str = "auto", force: bool = False, prefer_native: bool | None = None) -> str:
+    """Install the per-sweep exchange on `problem` for the current torch.distributed world.
+    Returns the transport used: "none" (world size 1, unless `force`), "xgmi-peer", "rccl-native" or "torch-hook".
+    `transport`: "auto" | "peer" | "rccl" | "hook" (env SBA_TRANSPORT overrides "auto").  The hook transport
+    requires the problem to have been created on torch's current stream."""
     import torch
     import torch.distributed as dist
 
-    world, rank = dist.get_world_size(), dist.get_rank()
-    if world == 1 and not force:
+    if prefer_native is not None:            # older call sites: True -> rccl, False -> hook
+        transport = "rccl" if prefer_native else "hook"
+    if transport == "auto":
+        transport = os.environ.get("SBA_TRANSPORT", "auto")
+    if dist.get_world_size() == 1 and not force:
         return "none"
-    dev = torch.device("cuda", torch.cuda.current_device())
-    if prefer_native:
-        uid, ok = bytes(128), 1
-        if rank == 0:
-            try:
-                uid = api.comm_unique_id()
-            except api.SbaError:
-                ok = 0
-        t = torch.tensor([ok] + list(uid), dtype=torch.int32, device=dev)
-        dist.broadcast(t, 0)
-        vals = t.cpu().tolist()
-        if vals[0] == 1:
-            problem.comm_init_rank(world, rank, bytes(vals[1:]))
+    if transport in ("auto", "peer"):
+        if _try_peer(problem, torch, dist):
+            return "xgmi-peer"
+        if transport == "peer":
+            raise RuntimeError("direct peer exchange could not be set up on every rank")
+    if transport in ("auto", "rccl"):
+        if _try_rccl(problem, torch, dist):
             return "rccl-native"
+        if transport == "rccl":
+            raise RuntimeError("RCCL unique id could not be created")
+    dev = torch.device("cuda", torch.cuda.current_device())
     pack = torch.as_tensor(_DevicePack(problem.pack_device_ptr, 24), device=dev)
 
     def hook(_ptr, _count, _stream):

@@ -1,0 +1,74 @@
+"""GPU (-m gpu): the direct peer exchange with SEVERAL PROCESSES ON ONE GPU (each rank opens the others' inboxes through
+HIP IPC; on a multi-GPU node the same stores travel over xGMI).  Control messages go through a gloo process group (an
+NCCL group cannot place several ranks on one device).  Checks: set-up + self-test, sharded sweeps == single-process
+sweep, every rank obtains the bit-identical pack, the LM runs in lock-step to the single-process answer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import REL_TOL_F64, ROOT
+from spherical_bundle_adjuster_amd import api, synthetic
+
+pytestmark = pytest.mark.gpu
+
+N = 60001
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from spherical_bundle_adjuster_amd import api as A, distributed, synthetic as syn
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        c = syn.full_rt(N, seed=77)
+        lo, hi = syn.shard_range(N, rank, world)
+        with A.Problem(0) as p:
+            p.upload(c.x1[lo:hi], c.x2[lo:hi], c.d12[lo:hi])
+            used = distributed.attach(p, transport="peer")
+            packs = [p.eval_pack(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH) for _ in range(5)]
+            packs.append(p.eval_steps(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH, steps=20)[0])
+            r, t, s = p.solve(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH)
+            tr, _, _ = p.solve(A.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
+            dist.barrier()
+            p.peer_disable()
+        q.put((rank, used, packs, r, t, s.num_iterations, tr))
+    except Exception as e:      # surface the failure in the parent instead of a silent timeout
+        import traceback
+        q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_exchange_processes_on_one_gpu(world):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda x: x[0])
+    [p.join(60) for p in procs]
+    for r in res:
+        assert r[1] == "xgmi-peer", r[2] if r[1] == "ERROR" else r[1]
+    c = synthetic.full_rt(N, seed=77)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, c.d12)
+        single = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        tr1, _, _ = p.solve(api.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
+    for rank, used, packs, r, t, iters, tr in res:
+        for pk in packs:
+            assert np.array_equal(pk, res[0][2][0])                         # bit-identical on every rank, every repeat
+        assert np.abs(packs[0] - single).max() <= REL_TOL_F64 * np.abs(single).max()
+        assert np.array_equal(r, res[0][3]) and np.array_equal(t, res[0][4])   # lock-step LM
+        assert iters == s1.num_iterations and np.abs(r - r1).max() <= 1e-11 and np.abs(t - t1).max() <= 1e-11
+        assert np.abs(tr - tr1).max() <= 1e-11
