@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10_000_000, help="correspondences per GPU")
+    ap.add_argument("--matches", "--n", dest="n", type=int, default=10_000_000, help="correspondences per GPU "
+                    "(use --matches under torch.distributed.run: its own parser trips over --n)")
     ap.add_argument("--workload", choices=["rt", "rot"], default="rt",
                     help="rt = config C3 (full R|t, per-match depths); rot = config C2 shape (rotation-only)")
     ap.add_argument("--store", choices=["f64", "f32"], default="f64")
@@ -120,12 +121,19 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # SBA_BENCH_ONE_GPU=1: rehearsal of the N > 1 code path on a box with ONE GPU (all ranks on device 0, gloo for
+    # the control messages; an NCCL group cannot place several ranks on one device).  Not a measurement.
+    rehearsal = os.environ.get("SBA_BENCH_ONE_GPU") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     rt = a.workload == "rt"
     mode = api.MODE_RT if rt else api.MODE_ROT
@@ -139,7 +147,7 @@ def main():
     # hook transport needs the problem on torch's current stream; native/none use the shim's own stream
     use_hook = world > 1 and a.transport == "hook"
     stream = torch.cuda.current_stream().cuda_stream if use_hook else None
-    p = api.Problem(local_rank, stream=stream)
+    p = api.Problem(device_index, stream=stream)
     p.set_kernel(api.KERNEL_EXPLICIT if a.kernel == "explicit" else api.KERNEL_FACTORED)
     t_up = time.perf_counter()
     p.upload(c.x1, c.x2, c.d12 if rt else None, store=store)      # host cv::Point3d-layout arrays -> device planes
@@ -166,7 +174,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -187,7 +195,7 @@ def main():
             "metric": "residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" + (" (ONE-GPU REHEARSAL of the multi-rank path: not a measurement)" if rehearsal else ""),
             "config": {"workload": ("10M synthetic unit-sphere correspondences per GPU, full R|t sweep, per-match "
                                     "depths (BASELINE config C3)" if rt and a.n == 10_000_000 else
                                     f"{a.n} synthetic correspondences per GPU, {a.workload} sweep"),
