@@ -142,6 +142,10 @@ struct sba_problem {
   size_t plane_elems = 0;     // allocated elements per plane (n rounded up to a whole vector)
   void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* dplane[2] = {nullptr, nullptr};
+  void* plane_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // hipMalloc'ed blocks
+  size_t plane_stagger = 4352; // SBA_PLANE_STAGGER: plane k starts k * 4352 B (17 x 256 B) into its allocation, so equal
+                               // element indices of the 8 streams differ in their low address bits (measured 0-4 %
+                               // faster with f64 planes, 3-5 % with f32 planes; never slower)
 
   double* partials = nullptr;  // [max_grid][24]
   int max_grid = 0;
@@ -172,14 +176,12 @@ struct sba_problem {
 namespace {
 
 int free_planes(sba_problem* p) {
-  for (auto& c : p->coord) {
-    if (c) SBA_HIP_TRY(hipFree(c));
-    c = nullptr;
+  for (auto& b : p->plane_base) {
+    if (b) SBA_HIP_TRY(hipFree(b));
+    b = nullptr;
   }
-  for (auto& d : p->dplane) {
-    if (d) SBA_HIP_TRY(hipFree(d));
-    d = nullptr;
-  }
+  for (auto& c : p->coord) c = nullptr;
+  for (auto& d : p->dplane) d = nullptr;
   p->uploaded = false;
   p->n = 0;
   p->plane_elems = 0;
@@ -194,14 +196,19 @@ int alloc_planes(sba_problem* p, size_t n, bool with_d12, int store) {
   // whole 16-byte vectors, plus one spare vector so that the ragged tail load stays in bounds
   const size_t ppt = static_cast<size_t>(sba::points_per_lane(store));
   const size_t elems = ((n + ppt - 1) / ppt + 1) * ppt;
-  for (auto& c : p->coord) {
-    SBA_HIP_TRY(hipMalloc(&c, elems * esz));
-    SBA_HIP_TRY(hipMemsetAsync(c, 0, elems * esz, p->stream));
+  // Each plane sits at offset k * plane_stagger inside its own allocation (16-byte aligned), so that equal element
+  // indices of different planes do not share the low address bits.
+  const size_t pad = 8 * p->plane_stagger;
+  for (int k = 0; k < 6; ++k) {
+    SBA_HIP_TRY(hipMalloc(&p->plane_base[k], elems * esz + pad));
+    SBA_HIP_TRY(hipMemsetAsync(p->plane_base[k], 0, elems * esz + pad, p->stream));
+    p->coord[k] = static_cast<char*>(p->plane_base[k]) + k * p->plane_stagger;
   }
   if (with_d12)
-    for (auto& d : p->dplane) {
-      SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), elems * 8));
-      SBA_HIP_TRY(hipMemsetAsync(d, 0, elems * 8, p->stream));
+    for (int k = 0; k < 2; ++k) {
+      SBA_HIP_TRY(hipMalloc(&p->plane_base[6 + k], elems * 8 + pad));
+      SBA_HIP_TRY(hipMemsetAsync(p->plane_base[6 + k], 0, elems * 8 + pad, p->stream));
+      p->dplane[k] = reinterpret_cast<double*>(static_cast<char*>(p->plane_base[6 + k]) + (6 + k) * p->plane_stagger);
     }
   p->n = n;
   p->store = store;
@@ -398,6 +405,10 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
     if (std::strcmp(env, "explicit") == 0) p->kind = SBA_KERNEL_EXPLICIT;
   }
   std::memset(p->occ_cache, 0, sizeof(p->occ_cache));
+  if (const char* env = std::getenv("SBA_PLANE_STAGGER")) {
+    const long v = std::atol(env);
+    if (v >= 0 && v <= (1 << 20) && v % 16 == 0) p->plane_stagger = static_cast<size_t>(v);
+  }
   if (stream) {
     p->stream = static_cast<hipStream_t>(stream);
   } else {
@@ -510,9 +521,11 @@ int sba_problem_set_depths(sba_problem* p, const double* d12) {
   if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   SBA_HIP_TRY(hipSetDevice(p->device));
   if (!p->has_d12) {
-    for (auto& d : p->dplane) {
-      SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), std::max<size_t>(p->plane_elems, 1) * 8));
-      SBA_HIP_TRY(hipMemsetAsync(d, 0, std::max<size_t>(p->plane_elems, 1) * 8, p->stream));
+    const size_t pad = 8 * p->plane_stagger, bytes = std::max<size_t>(p->plane_elems, 1) * 8 + pad;
+    for (int k = 0; k < 2; ++k) {
+      SBA_HIP_TRY(hipMalloc(&p->plane_base[6 + k], bytes));
+      SBA_HIP_TRY(hipMemsetAsync(p->plane_base[6 + k], 0, bytes, p->stream));
+      p->dplane[k] = reinterpret_cast<double*>(static_cast<char*>(p->plane_base[6 + k]) + (6 + k) * p->plane_stagger);
     }
     p->has_d12 = true;
   }
