@@ -65,17 +65,18 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(c, mode, per_match, sample, seconds):
-    """Oracle (kind "port"): faithful per-match dual-number functor + per-match trig + Huber corrector,
-    OpenMP over all host cores, on the first `sample` correspondences of the same workload."""
+    """Oracle (kind "port"): faithful per-match dual-number functor + per-match trig + Huber corrector, J^T J / J^T e
+    accumulated in double (orc_eval_f64 -- the long-double accumulation of the checker is not what is timed), OpenMP
+    over the usable host cores, on the first `sample` correspondences of the same workload."""
     from oracle import oracle_py as orc
     n = min(sample, c.x1.shape[0])
     x1, x2 = c.x1[:n], c.x2[:n]
     d12 = c.d12[:n] if per_match else None
     cores = min(orc.num_procs(), usable_cores())
-    orc.evaluate(mode, x1[:10000], x2[:10000], c.rot_init, c.tran_init, d12=None if d12 is None else d12[:10000], threads=cores)
+    orc.evaluate_f64(mode, x1[:10000], x2[:10000], c.rot_init, c.tran_init, d12=None if d12 is None else d12[:10000], threads=cores)
     passes, t0 = 0, time.perf_counter()
     while True:
-        orc.evaluate(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12, threads=cores)
+        orc.evaluate_f64(mode, x1, x2, c.rot_init, c.tran_init, 1.0, 1.0, 1.0, d12, threads=cores)
         passes += 1
         el = time.perf_counter() - t0
         if el >= seconds or passes >= 50:
@@ -86,7 +87,7 @@ def cpu_baseline(c, mode, per_match, sample, seconds):
     hoisted = n / (time.perf_counter() - t0)
     return {"value": faithful, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"{passes} passes over the first {n} correspondences of the workload, faithful "
-                      f"dual-number loop (oracle/sba_oracle.cpp), {cores} OpenMP threads",
+                      f"dual-number loop with f64 accumulation (oracle/sba_oracle.cpp: evaluate_all_f64), {cores} OpenMP threads",
             "optimised_cpu_value": hoisted}
 
 

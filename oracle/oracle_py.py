@@ -127,6 +127,11 @@ def evaluate(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, delta=1.0, d12=None, threa
     return _eval(lib().orc_eval, mode, x1, x2, d12, rot, tran, d1, d2, delta, threads)
 
 
+def evaluate_f64(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, delta=1.0, d12=None, threads=0) -> Eval:
+    """The faithful loop with plain-double accumulation (what is TIMED as the CPU baseline)."""
+    return _eval(lib().orc_eval_f64, mode, x1, x2, d12, rot, tran, d1, d2, delta, threads)
+
+
 def evaluate_hoisted(mode, x1, x2, rot, tran, d1=1.0, d2=1.0, delta=1.0, d12=None, threads=0) -> Eval:
     """Optimised-CPU loop: rotation matrices hoisted, analytic per-match arithmetic in double."""
     return _eval(lib().orc_eval_hoisted, mode, x1, x2, d12, rot, tran, d1, d2, delta, threads)

@@ -209,6 +209,52 @@ void evaluate_all(int mode, int per_match_depth, const double* x1, const double*
   out->n_out = static_cast<double>(total.n_out);
 }
 
+// The same faithful per-block evaluation (dual numbers, per-match trig, Huber corrector) but accumulating in plain
+// double like Ceres' own linear-algebra back ends do: this is the TIMED cpu baseline of bench.py (the long-double
+// accumulation above is for checking, and x87 arithmetic would make the CPU look slower than it is).
+void evaluate_all_f64(int mode, int per_match_depth, const double* x1, const double* x2, const double* d12,
+                      size_t n, const double rot[3], const double tran[3], double d1, double d2, double delta,
+                      int threads, EvalOut* out) {
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_num_procs();
+#else
+  threads = 1;
+#endif
+  std::vector<EvalOut> part(static_cast<size_t>(threads));
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (int t = 0; t < threads; ++t) {
+    const size_t lo = n * static_cast<size_t>(t) / threads, hi = n * static_cast<size_t>(t + 1) / threads;
+    EvalOut acc;
+    std::memset(&acc, 0, sizeof(acc));
+    for (size_t i = lo; i < hi; ++i) {
+      const double a = per_match_depth ? d12[2 * i] : d1, b = per_match_depth ? d12[2 * i + 1] : d2;
+      double e[3], J[18];
+      point_residual_jacobian(mode, x1 + 3 * i, x2 + 3 * i, rot, tran, a, b, e, J);
+      const double s = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+      double rho[3] = {s, 1.0, 0.0};
+      if (delta > 0.0) huber_evaluate(delta, s, rho);
+      const double scale = std::sqrt(rho[1]);
+      for (int r = 0; r < 3; ++r) { e[r] *= scale; for (int k = 0; k < 6; ++k) J[6 * r + k] *= scale; }
+      for (int p = 0; p < 6; ++p) {
+        for (int q = p; q < 6; ++q) acc.H[6 * p + q] += J[p] * J[q] + J[6 + p] * J[6 + q] + J[12 + p] * J[12 + q];
+        acc.g[p] += J[p] * e[0] + J[6 + p] * e[1] + J[12 + p] * e[2];
+      }
+      acc.cost += 0.5 * rho[0];
+      acc.sum_w += rho[1];
+      acc.n_out += (delta > 0.0 && s > delta * delta) ? 1.0 : 0.0;
+    }
+    part[static_cast<size_t>(t)] = acc;
+  }
+  std::memset(out, 0, sizeof(*out));
+  for (int t = 0; t < threads; ++t) {
+    const EvalOut& a = part[static_cast<size_t>(t)];
+    for (int i = 0; i < 36; ++i) out->H[i] += a.H[i];
+    for (int i = 0; i < 6; ++i) out->g[i] += a.g[i];
+    out->cost += a.cost; out->sum_w += a.sum_w; out->n_out += a.n_out;
+  }
+  for (int p = 0; p < 6; ++p) for (int q = 0; q < p; ++q) out->H[6 * p + q] = out->H[6 * q + p];
+}
+
 // "Optimised CPU" baseline (BASELINE.md variant B): rotation and its derivative matrices hoisted out
 // of the loop (central differences are NOT used: the matrices come from dual numbers once), analytic
 // per-match arithmetic in plain double, OpenMP reduction.  Timed next to the faithful loop so the
@@ -351,6 +397,14 @@ void orc_eval(int mode, int per_match_depth, const double* x1, const double* x2,
               int threads, double* out45) {
   EvalOut o;
   evaluate_all(mode, per_match_depth, x1, x2, d12, n, rot, tran, d1, d2, delta, threads, &o);
+  std::memcpy(out45, &o, sizeof(o));
+}
+
+void orc_eval_f64(int mode, int per_match_depth, const double* x1, const double* x2, const double* d12,
+                  size_t n, const double* rot, const double* tran, double d1, double d2, double delta,
+                  int threads, double* out45) {
+  EvalOut o;
+  evaluate_all_f64(mode, per_match_depth, x1, x2, d12, n, rot, tran, d1, d2, delta, threads, &o);
   std::memcpy(out45, &o, sizeof(o));
 }
 

@@ -220,3 +220,13 @@ def test_matcher_coordinate_maps_oracle(oracle):
     assert np.allclose(e[:4, 1], H / 2, atol=1e-3)
     assert np.allclose(e[:4, 0], [W / 4, W / 2, 3 * W / 4, 0.0], atol=1e-3)
     assert e[4, 1] < 1e-3 and abs(e[5, 1] - H) < 1e-3
+
+
+def test_timed_cpu_baseline_variant_matches_checker(oracle):
+    """bench.py times evaluate_f64 (double accumulation); it must compute the same thing as the long-double checker."""
+    c = synthetic.full_rt(20000, seed=99)
+    for mode in (0, 1, 2):
+        a = oracle.evaluate(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12)
+        b = oracle.evaluate_f64(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12)
+        assert np.abs(a.H - b.H).max() <= 1e-12 * np.abs(a.H).max() and abs(a.cost - b.cost) <= 1e-12 * a.cost
+        assert np.abs(a.g - b.g).max() <= 1e-11 * max(np.abs(a.g).max(), 1e-300) and a.n_outlier == b.n_outlier
