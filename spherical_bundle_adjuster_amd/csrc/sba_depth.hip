@@ -8,8 +8,8 @@
 // tests are global.  depth_step_kernel therefore does, for every match in one pass: residuals + 5x2 Jacobian at the
 // current depths, the scaled damped 2x2 solve, the projected candidate, the candidate's cost, and contributes to
 // the six global reductions the host needs for Ceres' step logic (sba_shim.cpp: sba_problem_solve_depths).
-// One thread per match; 8-byte loads, lanes contiguous (512 B per wave instruction) -- trivially HBM-bound
-// (12 loads + 4 stores of 8 B per match and iteration).
+// Two matches per lane, 16-byte accesses (1 KiB per wave instruction) -- HBM-bound: 8-12 loads + 4-8 stores of
+// 8 B per match and iteration (96-128 B).
 #include "sba_device.hpp"
 
 namespace sba {
@@ -26,6 +26,31 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// Two consecutive matches per lane: 16-byte accesses on the f64 planes (coordinates with f64 storage, depths,
+// scaling, diagonal, candidates), 8-byte on f32 coordinate planes; the once-read streams are loaded non-temporally.
+template <typename ST> struct Pair;
+template <> struct Pair<double> {
+  static __device__ __forceinline__ void load(const void* plane, size_t pair, double out[2]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 r = __builtin_nontemporal_load(reinterpret_cast<const f4*>(plane) + pair);
+    const double2 q = *reinterpret_cast<const double2*>(&r);
+    out[0] = q.x; out[1] = q.y;
+  }
+};
+template <> struct Pair<float> {
+  static __device__ __forceinline__ void load(const void* plane, size_t pair, double out[2]) {
+    const float2 q = reinterpret_cast<const float2*>(plane)[pair];
+    out[0] = q.x; out[1] = q.y;
+  }
+};
+__device__ __forceinline__ void load_pair_f64(const double* plane, size_t pair, double out[2]) {
+  const double2 q = reinterpret_cast<const double2*>(plane)[pair];
+  out[0] = q.x; out[1] = q.y;
+}
+__device__ __forceinline__ void store_pair_f64(double* plane, size_t pair, double a, double b) {
+  reinterpret_cast<double2*>(plane)[pair] = make_double2(a, b);
+}
+
 template <typename ST>
 __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
                                                         const double* __restrict__ d2,
@@ -35,56 +60,71 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
                                                         DepthParams P, double* __restrict__ partials) {
   __shared__ double red[4][8];
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gmax = 0;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < P.n; i += stride) {
-    const double x = static_cast<const ST*>(pl.x1[0])[i], y = static_cast<const ST*>(pl.x1[1])[i],
-                 z = static_cast<const ST*>(pl.x1[2])[i];
-    const double u = static_cast<const ST*>(pl.x2[0])[i], v = static_cast<const ST*>(pl.x2[1])[i],
-                 w = static_cast<const ST*>(pl.x2[2])[i];
-    const double a = d1[i], b = d2[i];
-    // q = R x1 ; e = b x2 - a q + t                                                   (.cpp:1008-1027)
-    const double q0 = P.R[0] * x + P.R[1] * y + P.R[2] * z;
-    const double q1 = P.R[3] * x + P.R[4] * y + P.R[5] * z;
-    const double q2 = P.R[6] * x + P.R[7] * y + P.R[8] * z;
-    const double e0 = b * u - a * q0 + P.t[0], e1 = b * v - a * q1 + P.t[1], e2 = b * w - a * q2 + P.t[2];
-    const double r4 = P.lambda * exp(-P.c * a), r5 = P.lambda * exp(-P.c * b);       // .cpp:1028-1029
-    cost += 0.5 * (e0 * e0 + e1 * e1 + e2 * e2 + r4 * r4 + r5 * r5);
-    // J = [[-q, x2], [-c r4, 0], [0, -c r5]]
-    const double j41 = -P.c * r4, j52 = -P.c * r5;
-    const double qq = q0 * q0 + q1 * q1 + q2 * q2, qx = q0 * u + q1 * v + q2 * w, xx = u * u + v * v + w * w;
-    const double qe = q0 * e0 + q1 * e1 + q2 * e2, xe = u * e0 + v * e1 + w * e2;
-    const double h11 = qq + j41 * j41, h12 = -qx, h22 = xx + j52 * j52;
-    const double g1 = -qe + j41 * r4, g2 = xe + j52 * r5;
-    // projected gradient norm of the bounded problem: |x - P(x - g)|_inf
-    gmax = fmax(gmax, fmax(fabs(a - fmax(a - g1, 0.0)), fabs(b - fmax(b - g2, 0.0))));
-    double s1, s2;
-    if (P.first_iteration) {
-      s1 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h11)) : 1.0;
-      s2 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h22)) : 1.0;
-      sc1[i] = s1; sc2[i] = s2;
-    } else {
-      s1 = sc1[i]; s2 = sc2[i];
+  for (size_t pr = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; pr < npairs; pr += stride) {
+    double X[2], Y[2], Z[2], U[2], V[2], W[2], A[2], B[2], S1[2], S2[2], DG1[2], DG2[2];
+    Pair<ST>::load(pl.x1[0], pr, X); Pair<ST>::load(pl.x1[1], pr, Y); Pair<ST>::load(pl.x1[2], pr, Z);
+    Pair<ST>::load(pl.x2[0], pr, U); Pair<ST>::load(pl.x2[1], pr, V); Pair<ST>::load(pl.x2[2], pr, W);
+    load_pair_f64(d1, pr, A); load_pair_f64(d2, pr, B);
+    if (!P.first_iteration) { load_pair_f64(sc1, pr, S1); load_pair_f64(sc2, pr, S2); }
+    if (P.reuse_diagonal) { load_pair_f64(dg1, pr, DG1); load_pair_f64(dg2, pr, DG2); }
+    double NA[2], NB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool valid = 2 * pr + h < P.n;
+      const double x = X[h], y = Y[h], z = Z[h], u = U[h], v = V[h], w = W[h], a = A[h], b = B[h];
+      // q = R x1 ; e = b x2 - a q + t                                                   (.cpp:1008-1027)
+      const double q0 = P.R[0] * x + P.R[1] * y + P.R[2] * z;
+      const double q1 = P.R[3] * x + P.R[4] * y + P.R[5] * z;
+      const double q2 = P.R[6] * x + P.R[7] * y + P.R[8] * z;
+      const double e0 = b * u - a * q0 + P.t[0], e1 = b * v - a * q1 + P.t[1], e2 = b * w - a * q2 + P.t[2];
+      const double r4 = P.lambda * exp(-P.c * a), r5 = P.lambda * exp(-P.c * b);       // .cpp:1028-1029
+      // J = [[-q, x2], [-c r4, 0], [0, -c r5]]
+      const double j41 = -P.c * r4, j52 = -P.c * r5;
+      const double qq = q0 * q0 + q1 * q1 + q2 * q2, qx = q0 * u + q1 * v + q2 * w, xx = u * u + v * v + w * w;
+      const double qe = q0 * e0 + q1 * e1 + q2 * e2, xe = u * e0 + v * e1 + w * e2;
+      const double h11 = qq + j41 * j41, h12 = -qx, h22 = xx + j52 * j52;
+      const double g1 = -qe + j41 * r4, g2 = xe + j52 * r5;
+      double s1, s2;
+      if (P.first_iteration) {
+        s1 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h11)) : 1.0;
+        s2 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h22)) : 1.0;
+        S1[h] = s1; S2[h] = s2;
+      } else {
+        s1 = S1[h]; s2 = S2[h];
+      }
+      const double H11 = s1 * h11 * s1, H12 = s1 * h12 * s2, H22 = s2 * h22 * s2, G1 = s1 * g1, G2 = s2 * g2;
+      double D1, D2;
+      if (P.reuse_diagonal) {
+        D1 = DG1[h]; D2 = DG2[h];
+      } else {
+        D1 = fmin(fmax(H11, P.min_diagonal), P.max_diagonal);
+        D2 = fmin(fmax(H22, P.min_diagonal), P.max_diagonal);
+        DG1[h] = D1; DG2[h] = D2;
+      }
+      const double A11 = H11 + D1 / P.radius, A22 = H22 + D2 / P.radius, A12 = H12;
+      const double det = A11 * A22 - A12 * A12;
+      const double y1 = (-G1 * A22 + G2 * A12) / det, y2 = (-G2 * A11 + G1 * A12) / det;
+      const double na = fmax(a + s1 * y1, 0.0), nb = fmax(b + s2 * y2, 0.0);   // Plus + projection onto d >= 0
+      NA[h] = na; NB[h] = nb;
+      const double f0 = nb * u - na * q0 + P.t[0], f1 = nb * v - na * q1 + P.t[1], f2 = nb * w - na * q2 + P.t[2];
+      const double f4 = P.lambda * exp(-P.c * na), f5 = P.lambda * exp(-P.c * nb);
+      if (valid) {     // the padding element of an odd-sized problem contributes nothing
+        cost += 0.5 * (e0 * e0 + e1 * e1 + e2 * e2 + r4 * r4 + r5 * r5);
+        // projected gradient norm of the bounded problem: |x - P(x - g)|_inf
+        gmax = fmax(gmax, fmax(fabs(a - fmax(a - g1, 0.0)), fabs(b - fmax(b - g2, 0.0))));
+        model += -(G1 * y1 + G2 * y2) - 0.5 * (H11 * y1 * y1 + 2.0 * H12 * y1 * y2 + H22 * y2 * y2);
+        step2 += (na - a) * (na - a) + (nb - b) * (nb - b);
+        x2n += a * a + b * b;
+        cand_cost += 0.5 * (f0 * f0 + f1 * f1 + f2 * f2 + f4 * f4 + f5 * f5);
+      } else {
+        NA[h] = 0.0; NB[h] = 0.0;   // keep the padding zero
+      }
     }
-    const double H11 = s1 * h11 * s1, H12 = s1 * h12 * s2, H22 = s2 * h22 * s2, G1 = s1 * g1, G2 = s2 * g2;
-    double D1, D2;
-    if (P.reuse_diagonal) {
-      D1 = dg1[i]; D2 = dg2[i];
-    } else {
-      D1 = fmin(fmax(H11, P.min_diagonal), P.max_diagonal);
-      D2 = fmin(fmax(H22, P.min_diagonal), P.max_diagonal);
-      dg1[i] = D1; dg2[i] = D2;
-    }
-    const double A11 = H11 + D1 / P.radius, A22 = H22 + D2 / P.radius, A12 = H12;
-    const double det = A11 * A22 - A12 * A12;
-    const double y1 = (-G1 * A22 + G2 * A12) / det, y2 = (-G2 * A11 + G1 * A12) / det;
-    model += -(G1 * y1 + G2 * y2) - 0.5 * (H11 * y1 * y1 + 2.0 * H12 * y1 * y2 + H22 * y2 * y2);
-    const double na = fmax(a + s1 * y1, 0.0), nb = fmax(b + s2 * y2, 0.0);   // Plus + projection onto d >= 0
-    c1[i] = na; c2[i] = nb;
-    step2 += (na - a) * (na - a) + (nb - b) * (nb - b);
-    x2n += a * a + b * b;
-    const double f0 = nb * u - na * q0 + P.t[0], f1 = nb * v - na * q1 + P.t[1], f2 = nb * w - na * q2 + P.t[2];
-    const double f4 = P.lambda * exp(-P.c * na), f5 = P.lambda * exp(-P.c * nb);
-    cand_cost += 0.5 * (f0 * f0 + f1 * f1 + f2 * f2 + f4 * f4 + f5 * f5);
+    store_pair_f64(c1, pr, NA[0], NA[1]); store_pair_f64(c2, pr, NB[0], NB[1]);
+    if (P.first_iteration) { store_pair_f64(sc1, pr, S1[0], S1[1]); store_pair_f64(sc2, pr, S2[0], S2[1]); }
+    if (!P.reuse_diagonal) { store_pair_f64(dg1, pr, DG1[0], DG1[1]); store_pair_f64(dg2, pr, DG2[0], DG2[1]); }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double r[6] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),

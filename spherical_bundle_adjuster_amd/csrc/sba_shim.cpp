@@ -841,7 +841,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&work), 6 * elems * sizeof(double)));
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
          *dg2 = work + 5 * elems;
-  const int grid = static_cast<int>(std::min<size_t>((n + 255) / 256, static_cast<size_t>(p->num_cus) * 8));
+  const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256, static_cast<size_t>(p->num_cus) * 8));
   double *partials = nullptr, *out_dev = nullptr;
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&partials), static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
   SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), 8 * sizeof(double)));
