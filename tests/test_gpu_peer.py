@@ -72,3 +72,28 @@ def test_peer_exchange_processes_on_one_gpu(world):
         assert np.array_equal(r, res[0][3]) and np.array_equal(t, res[0][4])   # lock-step LM
         assert iters == s1.num_iterations and np.abs(r - r1).max() <= 1e-11 and np.abs(t - t1).max() <= 1e-11
         assert np.abs(tr - tr1).max() <= 1e-11
+
+
+def test_bench_multi_rank_rehearsal(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), in its
+    one-GPU rehearsal mode: the JSON contract, the transport agreement and the max-over-ranks timing must all work."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SBA_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup",
+           "2", "--matches", "200000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 prints ONE JSON line
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 10 and b["warmup"] == 2 and b["scaling"] == "weak"
+    assert b["config"]["allreduce"] == "xgmi-peer" and b["unit"] == "evals/s" and b["higher_is_better"] is True
+    assert abs(b["value"] - 2 * 200000 * 10 / (b["ms_per_step"] * 1e-3 * 10)) <= 1e-6 * b["value"]
+    assert b["lm"]["termination"].startswith("CONVERGENCE") and "cpu_baseline" not in b
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in b["roofline"]
