@@ -207,9 +207,10 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
 
   // stage the AoS arrays whole, then re-lay each pair out at its plane offset
   const size_t base = offsets[0];
-  double* stage = nullptr;
   if (total > 0) {
-    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&stage), total * 3 * sizeof(double)));
+    sba::DeviceBuffer stage_buf;
+    SBA_TRY_HIP(stage_buf.alloc(total * 3 * sizeof(double)));
+    double* stage = stage_buf.as<double>();
     const double* src[2] = {left_xyz, right_xyz};
     for (int side = 0; side < 2; ++side) {
       SBA_TRY_HIP(hipMemcpyAsync(stage, src[side] + 3 * base, total * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -226,7 +227,6 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
                                               b->dplane[0], b->dplane[1], b->stream));
       SBA_TRY_HIP(hipStreamSynchronize(b->stream));
     }
-    SBA_TRY_HIP(hipFree(stage));
   }
   SBA_TRY_HIP(hipStreamSynchronize(b->stream));
   b->uploaded = true;

@@ -15,6 +15,17 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 void make_sweep_params(size_t n, int depth_mode, const double rot[3], const double tran[3], double d1, double d2,
                        double huber_delta, SweepParams* prm);
 
+// Scratch device memory that is released on every exit path.
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes > 0 ? bytes : 1); }
+  template <typename T> T* as() const { return static_cast<T*>(ptr); }
+};
+
 }  // namespace sba
 
 #define SBA_TRY_HIP(expr)                                                                            \

@@ -107,13 +107,12 @@ int with_device_copy(int device, void* host, size_t bytes, Launch&& launch) {
   int rc = require_device(device);
   if (rc) return rc;
   if (bytes == 0) return SBA_OK;
-  uint8_t* dev = nullptr;
-  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&dev), bytes));
-  SBA_TRY_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
-  launch(dev);
+  DeviceBuffer dev;
+  SBA_TRY_HIP(dev.alloc(bytes));
+  SBA_TRY_HIP(hipMemcpy(dev.ptr, host, bytes, hipMemcpyHostToDevice));
+  launch(dev.as<uint8_t>());
   SBA_TRY_HIP(hipGetLastError());
-  SBA_TRY_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
-  SBA_TRY_HIP(hipFree(dev));
+  SBA_TRY_HIP(hipMemcpy(host, dev.ptr, bytes, hipMemcpyDeviceToHost));
   return SBA_OK;
 }
 
@@ -153,17 +152,15 @@ int sba_crop_rotated_image(int device, const uint8_t* erp, int im_height, int im
   if (rc) return rc;
   const size_t in_bytes = static_cast<size_t>(im_height) * im_width * 3;
   const size_t px = static_cast<size_t>(im_height / 4) * im_width;
-  uint8_t *in_dev = nullptr, *out_dev = nullptr;
-  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&in_dev), in_bytes));
-  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&out_dev), px * 3));
-  SBA_TRY_HIP(hipMemcpy(in_dev, erp, in_bytes, hipMemcpyHostToDevice));
+  sba::DeviceBuffer in_dev, out_dev;
+  SBA_TRY_HIP(in_dev.alloc(in_bytes));
+  SBA_TRY_HIP(out_dev.alloc(px * 3));
+  SBA_TRY_HIP(hipMemcpy(in_dev.ptr, erp, in_bytes, hipMemcpyHostToDevice));
   const sba::Rot3 R = sba::pitch_rotation(pitch_deg);
   hipLaunchKernelGGL(sba::crop_rotated_kernel, dim3(static_cast<unsigned>((px + 255) / 256)), dim3(256), 0, nullptr,
-                     in_dev, im_height, im_width, R, out_dev);
+                     in_dev.as<uint8_t>(), im_height, im_width, R, out_dev.as<uint8_t>());
   SBA_TRY_HIP(hipGetLastError());
-  SBA_TRY_HIP(hipMemcpy(out, out_dev, px * 3, hipMemcpyDeviceToHost));
-  SBA_TRY_HIP(hipFree(in_dev));
-  SBA_TRY_HIP(hipFree(out_dev));
+  SBA_TRY_HIP(hipMemcpy(out, out_dev.ptr, px * 3, hipMemcpyDeviceToHost));
   return SBA_OK;
 }
 

@@ -477,8 +477,9 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
       // Bounded staging buffer: chunks of <= 4M correspondences (96 MB) go H2D then are re-laid
       // out as planes on the device.
       const size_t chunk = std::min<size_t>(n, size_t(4) << 20);
-      double* stage = nullptr;
-      SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage), chunk * 3 * sizeof(double)));
+      sba::DeviceBuffer stage_buf;
+      SBA_HIP_TRY(stage_buf.alloc(chunk * 3 * sizeof(double)));
+      double* stage = stage_buf.as<double>();
       const double* src[2] = {static_cast<const double*>(left), static_cast<const double*>(right)};
       for (int side = 0; side < 2; ++side)
         for (size_t first = 0; first < n; first += chunk) {
@@ -498,7 +499,6 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
           SBA_HIP_TRY(sba::launch_d12_to_planes(stage, m, first, p->dplane[0], p->dplane[1], p->stream));
           SBA_HIP_TRY(hipStreamSynchronize(p->stream));
         }
-      SBA_HIP_TRY(hipFree(stage));
     }
   }
   SBA_HIP_TRY(hipStreamSynchronize(p->stream));
@@ -530,12 +530,11 @@ int sba_problem_set_depths(sba_problem* p, const double* d12) {
     p->has_d12 = true;
   }
   if (p->n > 0) {
-    double* stage = nullptr;
-    SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage), p->n * 2 * sizeof(double)));
-    SBA_HIP_TRY(hipMemcpyAsync(stage, d12, p->n * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    SBA_HIP_TRY(sba::launch_d12_to_planes(stage, p->n, 0, p->dplane[0], p->dplane[1], p->stream));
+    sba::DeviceBuffer stage;
+    SBA_HIP_TRY(stage.alloc(p->n * 2 * sizeof(double)));
+    SBA_HIP_TRY(hipMemcpyAsync(stage.ptr, d12, p->n * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    SBA_HIP_TRY(sba::launch_d12_to_planes(stage.as<double>(), p->n, 0, p->dplane[0], p->dplane[1], p->stream));
     SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-    SBA_HIP_TRY(hipFree(stage));
   }
   return SBA_OK;
 }
@@ -837,15 +836,15 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   const size_t n = p->n, elems = std::max<size_t>(p->plane_elems, 2);
 
   // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, 8 results
-  double* work = nullptr;
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&work), 6 * elems * sizeof(double)));
+  sba::DeviceBuffer work_buf, partials_buf, out_buf;
+  SBA_HIP_TRY(work_buf.alloc(6 * elems * sizeof(double)));
+  double* work = work_buf.as<double>();
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
          *dg2 = work + 5 * elems;
   const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256, static_cast<size_t>(p->num_cus) * 8));
-  double *partials = nullptr, *out_dev = nullptr;
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&partials), static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), 8 * sizeof(double)));
-  auto cleanup = [&]() { (void)hipFree(work); (void)hipFree(partials); (void)hipFree(out_dev); };
+  SBA_HIP_TRY(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
+  SBA_HIP_TRY(out_buf.alloc(8 * sizeof(double)));
+  double *partials = partials_buf.as<double>(), *out_dev = out_buf.as<double>();
 
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
@@ -882,7 +881,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
 
   for (int it = 1;; ++it) {
     int rc = step();
-    if (rc) { cleanup(); return rc; }
+    if (rc) return rc;
     const double cost = out[0], model = out[1], cand_cost = out[2], gmax = out[5];
     if (it == 1) {
       sum->initial_cost = cost;
@@ -922,15 +921,13 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     SBA_HIP_TRY(hipMemcpyAsync(p->dplane[1], cur2, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
   if (d12_out && n > 0) {
-    double* aos = nullptr;
-    SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aos), 2 * n * sizeof(double)));
-    SBA_HIP_TRY(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos, p->stream));
-    SBA_HIP_TRY(hipMemcpyAsync(d12_out, aos, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    sba::DeviceBuffer aos;
+    SBA_HIP_TRY(aos.alloc(2 * n * sizeof(double)));
+    SBA_HIP_TRY(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos.as<double>(), p->stream));
+    SBA_HIP_TRY(hipMemcpyAsync(d12_out, aos.ptr, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-    SBA_HIP_TRY(hipFree(aos));
   }
   SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-  cleanup();
   if (rc_final != SBA_OK) return fail(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
   return SBA_OK;
 }
@@ -942,18 +939,17 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
   SBA_HIP_TRY(hipSetDevice(p->device));
   const size_t nquad = (p->n + 3) / 4;
   const int grid = static_cast<int>(std::min<size_t>((nquad + 63) / 64, static_cast<size_t>(p->num_cus) * 4));
-  double *partials = nullptr, *groups_dev = nullptr;
   const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&partials), static_cast<size_t>(std::max(grid, 1)) * gsz * sizeof(double)));
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&groups_dev), gsz * sizeof(double)));
+  sba::DeviceBuffer partials_buf, groups_buf;
+  SBA_HIP_TRY(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * gsz * sizeof(double)));
+  SBA_HIP_TRY(groups_buf.alloc(gsz * sizeof(double)));
+  double *partials = partials_buf.as<double>(), *groups_dev = groups_buf.as<double>();
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
   pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
   SBA_HIP_TRY(sba::launch_epipolar_moments(p->store, pl, p->n, partials, grid, groups_dev, p->stream));
   SBA_HIP_TRY(hipMemcpyAsync(groups, groups_dev, gsz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-  SBA_HIP_TRY(hipFree(partials));
-  SBA_HIP_TRY(hipFree(groups_dev));
   return SBA_OK;
 }
 
@@ -998,15 +994,13 @@ int sba_keypoints_to_sphere(int device, const void* keypoints, size_t n, size_t 
   int rc = require_device(device);
   if (rc) return rc;
   if (n == 0) return SBA_OK;
-  uint8_t* kp_dev = nullptr;
-  double* out_dev = nullptr;
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&kp_dev), n * stride_bytes));
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), n * 3 * sizeof(double)));
-  SBA_HIP_TRY(hipMemcpy(kp_dev, keypoints, n * stride_bytes, hipMemcpyHostToDevice));
-  SBA_HIP_TRY(sba::launch_keypoints_to_sphere(kp_dev, n, stride_bytes, im_width, im_height, out_dev, nullptr));
-  SBA_HIP_TRY(hipMemcpy(out_xyz, out_dev, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  SBA_HIP_TRY(hipFree(kp_dev));
-  SBA_HIP_TRY(hipFree(out_dev));
+  sba::DeviceBuffer kp_dev, out_dev;
+  SBA_HIP_TRY(kp_dev.alloc(n * stride_bytes));
+  SBA_HIP_TRY(out_dev.alloc(n * 3 * sizeof(double)));
+  SBA_HIP_TRY(hipMemcpy(kp_dev.ptr, keypoints, n * stride_bytes, hipMemcpyHostToDevice));
+  SBA_HIP_TRY(sba::launch_keypoints_to_sphere(kp_dev.as<uint8_t>(), n, stride_bytes, im_width, im_height,
+                                              out_dev.as<double>(), nullptr));
+  SBA_HIP_TRY(hipMemcpy(out_xyz, out_dev.ptr, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
   return SBA_OK;
 }
 
@@ -1032,15 +1026,13 @@ int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, i
   if (rc) return rc;
   const size_t in_bytes = static_cast<size_t>(im_height) * im_width * 3;
   const size_t out_bytes = static_cast<size_t>(cube_size) * 6 * cube_size * 3;
-  uint8_t *in_dev = nullptr, *out_dev = nullptr;
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&in_dev), in_bytes));
-  SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out_dev), out_bytes));
-  SBA_HIP_TRY(hipMemcpy(in_dev, erp, in_bytes, hipMemcpyHostToDevice));
-  rc = sba_equi2cube_device(device, nullptr, in_dev, im_height, im_width, cube_size, 1, out_dev);
+  sba::DeviceBuffer in_dev, out_dev;
+  SBA_HIP_TRY(in_dev.alloc(in_bytes));
+  SBA_HIP_TRY(out_dev.alloc(out_bytes));
+  SBA_HIP_TRY(hipMemcpy(in_dev.ptr, erp, in_bytes, hipMemcpyHostToDevice));
+  rc = sba_equi2cube_device(device, nullptr, in_dev.ptr, im_height, im_width, cube_size, 1, out_dev.ptr);
   if (rc) return rc;
-  SBA_HIP_TRY(hipMemcpy(out, out_dev, out_bytes, hipMemcpyDeviceToHost));
-  SBA_HIP_TRY(hipFree(in_dev));
-  SBA_HIP_TRY(hipFree(out_dev));
+  SBA_HIP_TRY(hipMemcpy(out, out_dev.ptr, out_bytes, hipMemcpyDeviceToHost));   // synchronises with the null stream
   return SBA_OK;
 }
 
