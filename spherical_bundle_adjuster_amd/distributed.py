@@ -112,6 +112,10 @@ def attach(problem: api.Problem, transport: str = "auto", force: bool = False, p
             return "rccl-native"
         if transport == "rccl":
             raise RuntimeError("RCCL unique id could not be created")
+    return _install_hook(problem, torch, dist)
+
+
+def _install_hook(problem: api.Problem, torch, dist) -> str:
     dev = torch.device("cuda", torch.cuda.current_device())
     pack = torch.as_tensor(_DevicePack(problem.pack_device_ptr, 24), device=dev)
 
