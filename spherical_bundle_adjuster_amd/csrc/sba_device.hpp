@@ -58,10 +58,6 @@ struct SweepOut {
 hipError_t launch_sweep(int mode, int depth, int store, int kind, const Planes& pl, const SweepParams& prm,
                         const SweepOut& out, int grid, hipStream_t stream);
 hipError_t sweep_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
-// Folds partials[nblocks][kRow] into pack_out[24]; with pack_host_dev != nullptr also publishes the pack to mapped
-// pinned host memory followed by `seq` at [24] for the host to poll.
-hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
-                           unsigned long long seq, hipStream_t stream);
 // Direct peer exchange (all-reduce of the pack over IPC-mapped inboxes, see peer_exchange_kernel).
 constexpr int kMaxPeers = 8;
 constexpr size_t kInboxDoubles = 2 * kMaxPeers * 32;   // [parity][source rank][32] = 4 KiB per rank
@@ -73,6 +69,12 @@ struct PeerInboxes {
 hipError_t launch_peer_exchange(const double* pack_local, const PeerInboxes& px, unsigned long long xseq,
                                 double* pack_out, double* pack_host_dev, unsigned long long host_seq,
                                 unsigned long long spin_limit, hipStream_t stream);
+// Folds partials[nblocks][kRow] into pack_out[24].  px != nullptr: the same launch then all-reduces the pack across
+// ranks (peer exchange, sequence number xseq).  pack_host_dev != nullptr: ... and publishes it to mapped pinned host
+// memory followed by `seq` at [24] for the host to poll.
+hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
+                           unsigned long long seq, const PeerInboxes* px, unsigned long long xseq,
+                           unsigned long long spin_limit, hipStream_t stream);
 
 // pack_dev[24] -> mapped pinned host memory, then `seq` at pack_host[24] (64-bit) for the host to poll.
 hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,

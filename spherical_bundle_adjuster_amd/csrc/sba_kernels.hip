@@ -512,55 +512,6 @@ __global__ __launch_bounds__(64) void batch_finalize_kernel(const double* __rest
   packs[static_cast<size_t>(pair) * 24 + slot] = (s0 + s1) + (s2 + s3);
 }
 
-// Fold partials[nblocks][24] in a fixed order.  1024 threads = 32 slots x 32 groups: group g sums
-// blocks g, g+32, ... for its slot (4 independent chains so the loads pipeline), then the 32 groups are
-// summed serially per slot.  Independent of timing, so results are run-to-run identical.
-__global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict__ partials,
-                                                        int nblocks, double* __restrict__ pack_out,
-                                                        double* __restrict__ pack_host, unsigned long long seq) {
-  __shared__ double part[32][33];
-  const int slot = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (slot < 24) {
-    int b = grp;
-    for (; b + 96 < nblocks; b += 128) {
-      s0 += partials[static_cast<size_t>(b) * kRow + slot];
-      s1 += partials[static_cast<size_t>(b + 32) * kRow + slot];
-      s2 += partials[static_cast<size_t>(b + 64) * kRow + slot];
-      s3 += partials[static_cast<size_t>(b + 96) * kRow + slot];
-    }
-    for (; b < nblocks; b += 32) s0 += partials[static_cast<size_t>(b) * kRow + slot];
-  }
-  part[grp][slot] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (threadIdx.x < 24) {
-    double tot = part[0][threadIdx.x];
-#pragma unroll
-    for (int g = 1; g < 32; ++g) tot += part[g][threadIdx.x];
-    pack_out[threadIdx.x] = tot;
-    if (pack_host) pack_host[threadIdx.x] = tot;
-  }
-  if (pack_host && threadIdx.x < 64) {   // wave 0 stored the pack: system-scope release, then the polled sequence number
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), seq, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-// After a collective (the all-reduced pack sits in device memory): one wave copies it into mapped pinned host
-// memory and releases the sequence number the host polls -- no blit kernel, no stream synchronisation.
-__global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ pack_dev,
-                                                     double* __restrict__ pack_host, unsigned long long seq) {
-  if (threadIdx.x < 24) pack_host[threadIdx.x] = pack_dev[threadIdx.x];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), seq, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // ---- direct peer exchange over xGMI: the all-reduce of the 24-double pack without a collective library ----------
 // Every rank owns an "inbox" in fine-grained device memory, mapped into all peers through HIP IPC:
 //     inbox[parity][source rank][32]   (24 doubles of payload, word 31 = sequence number; 256 B per slot)
@@ -572,20 +523,16 @@ __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ 
 // the slowest (it needs everybody's slot of round s before it can finish round s), so round s+1 never overwrites a
 // slot somebody still reads.  Spins are bounded; on a timeout word 25 of the host pack is set so the host reports
 // SBA_ERR_COMM instead of waiting forever.
-__global__ __launch_bounds__(64) void peer_exchange_kernel(const double* __restrict__ pack_local, PeerInboxes px,
-                                                           unsigned long long seq, double* __restrict__ pack_out,
-                                                           double* __restrict__ pack_host,
-                                                           unsigned long long host_seq,
-                                                           unsigned long long spin_limit) {
-  const int lane = threadIdx.x;
+// The exchange as executed by ONE wave (lanes 0..23 hold the local pack in `v`); returns the all-reduced value for the
+// lane and whether every source rank arrived in time.
+__device__ __forceinline__ double peer_exchange_wave(double v, const PeerInboxes& px, unsigned long long seq,
+                                                     unsigned long long spin_limit, int lane, bool* all_ok) {
   const unsigned parity = static_cast<unsigned>(seq & 1ull);
   const size_t my_slot = (static_cast<size_t>(parity) * kMaxPeers + px.rank) * 32;
-  // (1) payload to every inbox (own included): lanes 0..23 hold one double each
-  if (lane < 24) {
-    const double v = pack_local[lane];
+  // (1) payload to every inbox (own included)
+  if (lane < 24)
     for (int r = 0; r < px.nranks; ++r)
       __hip_atomic_store(px.inbox[r] + my_slot + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
   // (2) + (3): all payload stores of this wave are complete and visible before any sequence number is
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -603,28 +550,87 @@ __global__ __launch_bounds__(64) void peer_exchange_kernel(const double* __restr
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  const bool all_ok = __ballot(!ok) == 0ull;
+  *all_ok = __ballot(!ok) == 0ull;
   // (5)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  // (6)
-  if (lane < 24) {
-    double tot = 0.0;
+  // (6) rank-ordered sum
+  double tot = 0.0;
+  if (lane < 24)
     for (int r = 0; r < px.nranks; ++r)
       tot += __hip_atomic_load(px.inbox[px.rank] + (static_cast<size_t>(parity) * kMaxPeers + r) * 32 + lane,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    pack_out[lane] = tot;
-    if (pack_host) pack_host[lane] = tot;
+  return tot;
+}
+
+// (7) of the exchange / the single-GPU hand-over: lanes 0..23 of one wave store the pack into mapped pinned host
+// memory, word 25 = error flag, system-scope release, then the sequence number the host polls.
+__device__ __forceinline__ void publish_wave(double v, double* __restrict__ pack_host, unsigned long long host_seq,
+                                             bool ok, int lane) {
+  if (lane < 24) pack_host[lane] = v;
+  if (lane == 0) reinterpret_cast<unsigned long long*>(pack_host)[25] = ok ? 0ull : 1ull;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), host_seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// After a library collective (the all-reduced pack sits in device memory): one wave hands it to the host.
+__global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ pack_dev,
+                                                     double* __restrict__ pack_host, unsigned long long seq) {
+  const int lane = threadIdx.x;
+  publish_wave(lane < 24 ? pack_dev[lane] : 0.0, pack_host, seq, true, lane);
+}
+
+__global__ __launch_bounds__(64) void peer_exchange_kernel(const double* __restrict__ pack_local, PeerInboxes px,
+                                                           unsigned long long seq, double* __restrict__ pack_out,
+                                                           double* __restrict__ pack_host,
+                                                           unsigned long long host_seq,
+                                                           unsigned long long spin_limit) {
+  const int lane = threadIdx.x;
+  bool all_ok = true;
+  const double tot = peer_exchange_wave(lane < 24 ? pack_local[lane] : 0.0, px, seq, spin_limit, lane, &all_ok);
+  if (lane < 24) pack_out[lane] = tot;
+  if (pack_host) publish_wave(tot, pack_host, host_seq, all_ok, lane);
+}
+
+// Fold partials[nblocks][kRow] in a fixed order.  1024 threads = 32 slots x 32 groups: group g sums blocks g, g+32, ...
+// for its slot (4 independent chains so the loads pipeline), then the 32 groups are summed serially per slot.
+// Independent of timing, so results are run-to-run identical.  Wave 0 then hands the pack on: with px.nranks > 0 it
+// first runs the peer exchange (all-reduce across ranks), and with pack_host != nullptr it publishes the result to the
+// host -- one launch after the sweep covers reduction, exchange and hand-over.
+__global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict__ partials,
+                                                        int nblocks, double* __restrict__ pack_out,
+                                                        double* __restrict__ pack_host, unsigned long long seq,
+                                                        PeerInboxes px, unsigned long long xseq,
+                                                        unsigned long long spin_limit) {
+  __shared__ double part[32][33];
+  const int slot = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (slot < 24) {
+    int b = grp;
+    for (; b + 96 < nblocks; b += 128) {
+      s0 += partials[static_cast<size_t>(b) * kRow + slot];
+      s1 += partials[static_cast<size_t>(b + 32) * kRow + slot];
+      s2 += partials[static_cast<size_t>(b + 64) * kRow + slot];
+      s3 += partials[static_cast<size_t>(b + 96) * kRow + slot];
+    }
+    for (; b < nblocks; b += 32) s0 += partials[static_cast<size_t>(b) * kRow + slot];
   }
-  // (7)
-  if (pack_host) {
-    if (lane == 0)
-      reinterpret_cast<unsigned long long*>(pack_host)[25] = all_ok ? 0ull : 1ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), host_seq, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+  part[grp][slot] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x >= 64) return;          // wave 0 finishes alone
+  const int lane = threadIdx.x;
+  double tot = 0.0;
+  if (lane < 24) {
+    tot = part[0][lane];
+#pragma unroll
+    for (int g = 1; g < 32; ++g) tot += part[g][lane];
   }
+  bool ok = true;
+  if (px.nranks > 0) tot = peer_exchange_wave(tot, px, xseq, spin_limit, lane, &ok);
+  if (lane < 24) pack_out[lane] = tot;
+  if (pack_host) publish_wave(tot, pack_host, seq, ok, lane);
 }
 
 // ---- layout conversion at upload time (once per problem, not per LM iteration) ---------------
@@ -862,8 +868,14 @@ hipError_t launch_peer_exchange(const double* pack_local, const PeerInboxes& px,
 }
 
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
-                           unsigned long long seq, hipStream_t stream) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out, pack_host_dev, seq);
+                           unsigned long long seq, const PeerInboxes* px, unsigned long long xseq,
+                           unsigned long long spin_limit, hipStream_t stream) {
+  PeerInboxes none;
+  for (auto& q : none.inbox) q = nullptr;
+  none.nranks = 0;
+  none.rank = 0;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out, pack_host_dev, seq,
+                     px ? *px : none, xseq, spin_limit);
   return hipGetLastError();
 }
 

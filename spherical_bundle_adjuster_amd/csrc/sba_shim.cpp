@@ -288,16 +288,22 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   out.pack_host = (fused && to_host) ? p->pack_host_dev : nullptr;
   out.seq = p->seq;
   SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, out, grid, p->stream));
-  if (!fused)
-    SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
-                                     p->stream));
   if (p->peer_ready) {
-    // all-reduce by direct peer stores over xGMI + rank-ordered local sum; the same wave publishes to the host
+    // all-reduce by direct peer stores over xGMI + rank-ordered local sum; the exchanging wave publishes to the host.
+    // Two-kernel mode: the finalize kernel's wave 0 does fold, exchange and publication in ONE launch.
     if (p->publish) { ++p->seq; p->published = true; }
-    SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev,
-                                          p->publish ? p->pack_host_dev : nullptr, p->seq, p->peer_spin_limit, p->stream));
+    double* host = p->publish ? p->pack_host_dev : nullptr;
+    if (!fused)
+      SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, host, p->seq, &p->peers, ++p->xseq,
+                                       p->peer_spin_limit, p->stream));
+    else
+      SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev, host, p->seq,
+                                            p->peer_spin_limit, p->stream));
     return SBA_OK;
   }
+  if (!fused)
+    SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
+                                     nullptr, 0, 0, p->stream));
   if (p->comm) {
     Rccl& r = rccl();
     const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
