@@ -192,6 +192,14 @@ int sba_problem_upload(sba_problem* p, const double* left_xyz, const double* rig
 int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const void* right_xyz_dev,
                               const void* d12_dev, size_t n, int store);
 
+/* Same, straight from the matcher's output: `left_keypoints[i]` / `right_keypoints[i]` are the MATCHED
+ * key-point records (cv::KeyPoint layout: the first two float32 of each record are pt.x, pt.y;
+ * stride_bytes = sizeof(cv::KeyPoint) = 28) of the two equirectangular images.  The pixel -> unit-sphere
+ * map of spherical_bundle_adjuster.cpp:271-298 runs on the device and writes the coordinate planes
+ * directly, so the host never materialises the cv::Point3d arrays.       */
+int sba_problem_upload_keypoints(sba_problem* p, const void* left_keypoints, const void* right_keypoints, size_t n,
+                                 size_t stride_bytes, int im_width, int im_height, const double* d12, int store);
+
 int sba_problem_size(const sba_problem* p, size_t* n);
 /* (Re)upload only the per-match depths d12 (double[2n], init_d layout) of the resident correspondences.    */
 int sba_problem_set_depths(sba_problem* p, const double* d12);

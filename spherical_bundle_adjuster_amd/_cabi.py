@@ -84,6 +84,7 @@ SIGNATURES = {
     "sba_problem_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
     "sba_problem_destroy": (C.c_int, [_vp]),
     "sba_problem_upload": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
+    "sba_problem_upload_keypoints": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp, C.c_int]),
     "sba_problem_upload_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int]),
     "sba_problem_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "sba_problem_set_kernel": (C.c_int, [_vp, C.c_int]),

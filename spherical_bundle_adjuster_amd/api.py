@@ -131,6 +131,25 @@ class Problem:
         cabi.check(self._lib, self._lib.sba_problem_upload(
             self._h, x1.ctypes.data_as(C.c_void_p), x2.ctypes.data_as(C.c_void_p), dp, n, store))
 
+    def upload_keypoints(self, left_kp: np.ndarray, right_kp: np.ndarray, im_width: int, im_height: int, d12=None,
+                         store: int = STORE_F64) -> None:
+        """Matched cv::KeyPoint-like records (first two float32 = pt.x, pt.y) of both images -> device planes,
+        pixel -> unit sphere computed on the device (reference .cpp:271-298)."""
+        kl, kr = np.ascontiguousarray(left_kp), np.ascontiguousarray(right_kp)
+        if kl.shape != kr.shape:
+            raise ValueError("left/right key-point arrays differ")
+        n = kl.shape[0]
+        stride = kl.strides[0] if n > 0 else 28
+        dp = None
+        if d12 is not None:
+            d = _f64(d12).reshape(-1, 2)
+            if d.shape[0] != n:
+                raise ValueError("d12 length differs")
+            dp = d.ctypes.data_as(C.c_void_p)
+        cabi.check(self._lib, self._lib.sba_problem_upload_keypoints(
+            self._h, kl.ctypes.data_as(C.c_void_p), kr.ctypes.data_as(C.c_void_p), n, stride, im_width, im_height, dp,
+            store))
+
     def upload_device(self, left_ptr: int, right_ptr: int, d12_ptr: int | None, n: int,
                       store: int = STORE_F64) -> None:
         cabi.check(self._lib, self._lib.sba_problem_upload_device(

@@ -129,6 +129,9 @@ hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double
 // pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
 hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride_bytes, double im_w,
                                       double im_h, double* out_xyz, hipStream_t stream);
+// ... fused with the upload: matched key-point records of both images -> the six coordinate planes (x1.xyz, x2.xyz)
+hipError_t launch_keypoints_to_planes(const uint8_t* kp_left, const uint8_t* kp_right, size_t n, size_t stride_bytes,
+                                      double im_w, double im_h, void* const planes[6], int store, hipStream_t stream);
 // ERP -> cubemap strip (equi2cube.cpp:12-302)
 hipError_t launch_equi2cube(const uint8_t* erp, int im_h, int im_w, int cube, int batch, uint8_t* out,
                             hipStream_t stream);

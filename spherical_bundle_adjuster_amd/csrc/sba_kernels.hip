@@ -676,6 +676,25 @@ __global__ void keypoints_to_sphere_kernel(const uint8_t* __restrict__ kp, size_
   out_xyz[3 * i + 2] = cc;
 }
 
+// Same map, fused with the upload: key-point records of BOTH images -> the six coordinate planes of a problem
+// (no host-side cv::Point3d arrays in between).
+template <typename ST>
+__global__ void keypoints_to_planes_kernel(const uint8_t* __restrict__ kp_left, const uint8_t* __restrict__ kp_right,
+                                           size_t n, size_t stride_bytes, double im_w, double im_h,
+                                           ST* __restrict__ x1x, ST* __restrict__ x1y, ST* __restrict__ x1z,
+                                           ST* __restrict__ x2x, ST* __restrict__ x2y, ST* __restrict__ x2z) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double kPi = 3.14159265358979323846;
+  const float* l = reinterpret_cast<const float*>(kp_left + i * stride_bytes);
+  const float* r = reinterpret_cast<const float*>(kp_right + i * stride_bytes);
+  const double lon1 = 2 * kPi * (static_cast<double>(l[0]) / im_w), col1 = kPi * (static_cast<double>(l[1]) / im_h);
+  const double lon2 = 2 * kPi * (static_cast<double>(r[0]) / im_w), col2 = kPi * (static_cast<double>(r[1]) / im_h);
+  const double s1 = sin(col1), s2 = sin(col2);
+  x1x[i] = static_cast<ST>(s1 * cos(lon1)); x1y[i] = static_cast<ST>(s1 * sin(lon1)); x1z[i] = static_cast<ST>(cos(col1));
+  x2x[i] = static_cast<ST>(s2 * cos(lon2)); x2y[i] = static_cast<ST>(s2 * sin(lon2)); x2z[i] = static_cast<ST>(cos(col2));
+}
+
 // ---- ERP -> cubemap strip (reference equi2cube.cpp:12-302) ----------------------------------------
 // Output strip is S x 6S, faces left,front,right,back,top,bottom (equi2cube.cpp:292-298).  Per
 // output pixel (i = row, j = column inside the face) the face-specific direction
@@ -914,6 +933,23 @@ hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride
   const unsigned grid = static_cast<unsigned>((n + 255) / 256);
   hipLaunchKernelGGL(keypoints_to_sphere_kernel, dim3(grid), dim3(256), 0, stream, kp, n, stride_bytes,
                      im_w, im_h, out_xyz);
+  return hipGetLastError();
+}
+
+hipError_t launch_keypoints_to_planes(const uint8_t* kp_left, const uint8_t* kp_right, size_t n, size_t stride_bytes,
+                                      double im_w, double im_h, void* const planes[6], int store, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+  if (store == 0)
+    hipLaunchKernelGGL((keypoints_to_planes_kernel<double>), dim3(grid), dim3(256), 0, stream, kp_left, kp_right, n,
+                       stride_bytes, im_w, im_h, static_cast<double*>(planes[0]), static_cast<double*>(planes[1]),
+                       static_cast<double*>(planes[2]), static_cast<double*>(planes[3]), static_cast<double*>(planes[4]),
+                       static_cast<double*>(planes[5]));
+  else
+    hipLaunchKernelGGL((keypoints_to_planes_kernel<float>), dim3(grid), dim3(256), 0, stream, kp_left, kp_right, n,
+                       stride_bytes, im_w, im_h, static_cast<float*>(planes[0]), static_cast<float*>(planes[1]),
+                       static_cast<float*>(planes[2]), static_cast<float*>(planes[3]), static_cast<float*>(planes[4]),
+                       static_cast<float*>(planes[5]));
   return hipGetLastError();
 }
 

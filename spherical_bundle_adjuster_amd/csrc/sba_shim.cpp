@@ -517,6 +517,31 @@ int sba_problem_upload(sba_problem* p, const double* left_xyz, const double* rig
   return upload_common(p, left_xyz, right_xyz, d12, n, store, false);
 }
 
+int sba_problem_upload_keypoints(sba_problem* p, const void* left_keypoints, const void* right_keypoints, size_t n,
+                                 size_t stride_bytes, int im_width, int im_height, const double* d12, int store) {
+  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  if (store != SBA_STORE_F64 && store != SBA_STORE_F32) return fail(SBA_ERR_INVALID_ARG, "bad store %d", store);
+  if (n > 0 && (!left_keypoints || !right_keypoints)) return fail(SBA_ERR_INVALID_ARG, "null key-point array");
+  if (stride_bytes < 8 || stride_bytes % 4 != 0) return fail(SBA_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 8");
+  if (im_width <= 0 || im_height <= 0) return fail(SBA_ERR_INVALID_ARG, "bad image size");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  int rc = alloc_planes(p, n, d12 != nullptr, store);
+  if (rc) return rc;
+  if (n > 0) {
+    sba::DeviceBuffer kl, kr;
+    SBA_HIP_TRY(kl.alloc(n * stride_bytes));
+    SBA_HIP_TRY(kr.alloc(n * stride_bytes));
+    SBA_HIP_TRY(hipMemcpyAsync(kl.ptr, left_keypoints, n * stride_bytes, hipMemcpyHostToDevice, p->stream));
+    SBA_HIP_TRY(hipMemcpyAsync(kr.ptr, right_keypoints, n * stride_bytes, hipMemcpyHostToDevice, p->stream));
+    SBA_HIP_TRY(sba::launch_keypoints_to_planes(kl.as<uint8_t>(), kr.as<uint8_t>(), n, stride_bytes, im_width, im_height,
+                                                p->coord, store, p->stream));
+    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  p->uploaded = true;
+  if (d12) return sba_problem_set_depths(p, d12);
+  return SBA_OK;
+}
+
 int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const void* right_xyz_dev,
                               const void* d12_dev, size_t n, int store) {
   return upload_common(p, left_xyz_dev, right_xyz_dev, d12_dev, n, store, true);

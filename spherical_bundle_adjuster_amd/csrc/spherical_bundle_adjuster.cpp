@@ -45,26 +45,19 @@ int spherical_bundle_adjuster::do_bundle_adjustment_from_matches(const std::vect
   if (match_size < 0 || static_cast<size_t>(match_size) > left_key.size() ||
       static_cast<size_t>(match_size) > right_key.size())
     return SBA_ERR_INVALID_ARG;
-  // pixel -> radian -> unit vector (.cpp:271-298), on the device
-  std::vector<cv::Point3d> key_point_left_rect(match_size), key_point_right_rect(match_size);
-  int rc = sba_keypoints_to_sphere(device, left_key.data(), match_size, sizeof(cv::KeyPoint), im_width,
-                                   im_height, reinterpret_cast<double*>(key_point_left_rect.data()));
-  if (rc) return rc;
-  rc = sba_keypoints_to_sphere(device, right_key.data(), match_size, sizeof(cv::KeyPoint), im_width, im_height,
-                               reinterpret_cast<double*>(key_point_right_rect.data()));
-  if (rc) return rc;
-
   std::cout << "Do bundle adjustment" << std::endl;                                     // .cpp:300
-  // The coordinates go to the device once; the initial guess and all three solve stages work on that copy.
+  // pixel -> radian -> unit vector (.cpp:271-298) runs on the device and writes the coordinate planes directly:
+  // the matched key-points go to the device once, the cv::Point3d arrays of the reference are never materialised on
+  // the host, and the initial guess and all three solve stages work on that one resident copy.
   if (!problem) {
-    rc = sba_problem_create(&problem, device, nullptr);
-    if (rc) return rc;
+    int rc0 = sba_problem_create(&problem, device, nullptr);
+    if (rc0) return rc0;
   }
-  rc = sba_problem_upload(problem, reinterpret_cast<const double*>(key_point_left_rect.data()),
-                          reinterpret_cast<const double*>(key_point_right_rect.data()), nullptr,
-                          static_cast<size_t>(match_size), SBA_STORE_F64);
+  int rc = sba_problem_upload_keypoints(problem, left_key.data(), right_key.data(), static_cast<size_t>(match_size),
+                                        sizeof(cv::KeyPoint), im_width, im_height, nullptr, SBA_STORE_F64);
   if (rc) return rc;
-  resident_left = key_point_left_rect.data();
+  std::vector<cv::Point3d> key_point_left_rect, key_point_right_rect;   // stay empty: the data is resident
+  resident_left = &key_point_left_rect;
   resident_n = match_size;
 
   // Initial values (.cpp:302-331).  Default: the 8-point consensus (initial_guess, .cpp:304), then
@@ -91,6 +84,8 @@ int spherical_bundle_adjuster::do_bundle_adjustment_from_matches(const std::vect
   options.verbose = 1;               // minimizer_progress_to_stdout, .cpp:337
 
   rc = solve_problem(options, key_point_left_rect, key_point_right_rect, init_rot, init_tran, init_d, match_size);
+  resident_left = nullptr;
+  resident_n = -1;
   if (rc) return rc;
 
   for (int i = 0; i < 3; ++i) { res.rot[i] = init_rot[i]; res.tran[i] = init_tran[i]; }
@@ -116,9 +111,12 @@ int spherical_bundle_adjuster::solve_problem(sba_lm_options& opt, std::vector<cv
   // One flat upload replaces the per-match `new AutoDiffCostFunction / new HuberLoss` of the four
   // add_residual loops (.cpp:870-889, :921-945, :978-1002, :1034-1063).  When do_bundle_adjustment_from_matches
   // already made these coordinates resident, only the depths (init_d) are sent.
-  if (resident_left == key_point_left_rect.data() && resident_n == match_num && match_num > 0) {
+  if (resident_left == &key_point_left_rect && resident_n == match_num && match_num > 0) {
     rc = sba_problem_set_depths(problem, reinterpret_cast<const double*>(init_d.data()));
   } else {
+    if (key_point_left_rect.size() < static_cast<size_t>(match_num) ||
+        key_point_right_rect.size() < static_cast<size_t>(match_num) || init_d.size() < static_cast<size_t>(match_num))
+      return SBA_ERR_INVALID_ARG;
     rc = sba_problem_upload(problem, reinterpret_cast<const double*>(key_point_left_rect.data()),
                             reinterpret_cast<const double*>(key_point_right_rect.data()),
                             match_num > 0 ? reinterpret_cast<const double*>(init_d.data()) : nullptr,

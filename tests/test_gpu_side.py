@@ -24,6 +24,38 @@ def test_keypoints_to_sphere(oracle):
     assert api.keypoints_to_sphere(kp[:0], W, H).shape == (0, 3)
 
 
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32])
+def test_upload_keypoints_fused(oracle, store):
+    """Matched key-point records -> device planes in one kernel: same sweep result as going through the host arrays."""
+    from helpers import REL_TOL_F64, REL_TOL_F32, assert_normal_eq_close
+    rng = np.random.default_rng(17)
+    n, W, H = 5003, 3840, 1920
+    kl = np.zeros((n, 7), dtype=np.float32)
+    kl[:, 0] = rng.uniform(0, W, n)
+    kl[:, 1] = rng.uniform(0.05 * H, 0.95 * H, n)
+    kr = kl.copy()
+    kr[:, :2] += rng.normal(0, 3.0, (n, 2)).astype(np.float32)
+    d12 = rng.uniform(0.5, 2.0, (n, 2))
+    rot, tran = [0.02, -0.01, 0.03], [0.1, 0.05, -0.2]
+    x1, x2 = oracle.keypoints_to_sphere(kl, W, H), oracle.keypoints_to_sphere(kr, W, H)
+    tol = REL_TOL_F64 if store == api.STORE_F64 else REL_TOL_F32
+    with api.Problem() as p:
+        p.upload_keypoints(kl, kr, W, H, d12=d12, store=store)
+        assert p.size == n
+        for mode in (api.MODE_ROT, api.MODE_TRAN, api.MODE_RT):
+            got = p.eval(mode, rot, tran, depth_mode=api.DEPTH_PER_MATCH)
+            assert_normal_eq_close(got, oracle.evaluate(mode, x1, x2, rot, tran, d12=d12), tol)
+        # identical bits to the two-step route (device pixel->sphere, then upload): same device arithmetic
+        fused = p.eval_pack(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)
+        p.upload(api.keypoints_to_sphere(kl, W, H), api.keypoints_to_sphere(kr, W, H), d12=d12, store=store)
+        two_step = p.eval_pack(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)
+        assert np.array_equal(fused, two_step)
+        p.upload_keypoints(kl[:0], kr[:0], W, H)
+        assert p.size == 0 and p.eval(api.MODE_RT, rot, tran).cost == 0.0
+        with pytest.raises(api.SbaError):
+            p.upload_keypoints(kl, kr, 0, H)
+
+
 @pytest.mark.parametrize("H,W,S", [(64, 128, 16), (480, 960, 150), (1920, 3840, 600), (100, 200, 33)])
 def test_equi2cube_bit_exact(oracle, H, W, S):
     """Byte-exact against the oracle (integer index work): every output pixel identical."""
