@@ -5,6 +5,8 @@
 //   build:  hipcc --offload-arch=gfx950 -O3 -o build/stream_probe tools/stream_probe.hip
 //   run:    build/stream_probe [n_matches=10000000] [launches=50]
 //
+// (A dynamically balanced tail -- 64-vector chunks handed out by one agent-scope atomic counter -- was measured with
+// an earlier version of this probe: ~10 ns per same-address ticket, 907 us for a fully dynamic 10M launch; dropped.)
 // Variants: grid size (blocks per CU), grid-stride vs per-block contiguous chunks, nt vs plain loads, 1 or 2 vectors
 // in flight per plane.  Per-block start/end times (s_memrealtime, 100 MHz) of the last launch show the ramp and the tail.
 #include <hip/hip_runtime.h>
@@ -86,62 +88,6 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(PlanePtrs pl, size_t nvec
   }
 }
 
-// Static grid-stride over the first `static_vec` vectors, then wave-granular dynamic chunks (64 vectors = 1 KiB per
-// plane) handed out by one atomic counter: waves that finish their static share early take more of the rest.  The
-// ticket for the next chunk is requested before the current chunk's loads, so its latency overlaps theirs.
-template <bool NT>
-__global__ __launch_bounds__(kBlock) void probe_dyn_kernel(PlanePtrs pl, size_t nvec, size_t static_vec,
-                                                            unsigned* __restrict__ counter, double* __restrict__ out,
-                                                            unsigned long long* __restrict__ clocks) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  const int lane = threadIdx.x & 63;
-  const unsigned nd = static_cast<unsigned>((nvec - static_vec + 63) / 64);
-  unsigned ticket = 0;
-  if (lane == 0) ticket = atomicAdd(counter, 1u);        // first dynamic chunk: latency hidden under the static part
-  double acc = 0.0;
-  {
-    size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
-    double2 cur[kPlanes];
-    if (p < static_vec)
-#pragma unroll
-      for (int k = 0; k < kPlanes; ++k) cur[k] = ld<NT>(pl.p[k] + p);
-    while (p < static_vec) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < kPlanes; ++k) s += cur[k].x * cur[k].y;
-      acc += s;
-      p += stride;
-      if (p < static_vec)
-#pragma unroll
-        for (int k = 0; k < kPlanes; ++k) cur[k] = ld<NT>(pl.p[k] + p);
-    }
-  }
-  unsigned c = __builtin_amdgcn_readfirstlane(ticket);
-  while (c < nd) {
-    unsigned nxt = 0;
-    if (lane == 0) nxt = atomicAdd(counter, 1u);
-    const size_t p = static_vec + static_cast<size_t>(c) * 64 + lane;
-    if (p < nvec) {
-      double2 v[kPlanes];
-#pragma unroll
-      for (int k = 0; k < kPlanes; ++k) v[k] = ld<NT>(pl.p[k] + p);
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < kPlanes; ++k) s += v[k].x * v[k].y;
-      acc += s;
-    }
-    c = __builtin_amdgcn_readfirstlane(nxt);
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    clocks[2 * blockIdx.x] = t0;
-    clocks[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-  }
-}
-
 typedef void (*Kern)(PlanePtrs, size_t, double*, unsigned long long*);
 
 struct Variant { const char* name; Kern k; };
@@ -206,48 +152,47 @@ int main(int argc, char** argv) {
                   " idle-before-end med %4.1f p90 %4.1f max %4.1f us\n",
                   v.name, bpc, us, n * 8.0 * kPlanes / us * 1e-3, (last - first) * 0.01, st[grid / 2], st[grid * 9 / 10],
                   st[grid - 1], en[grid / 2], en[grid * 9 / 10], en[grid - 1]);
+      if (bpc <= 2 && &v == &variants[0]) {   // is the finish-time spread systematic?  mean finish per XCD (block % 8) and per CU slot
+        double sum[8] = {0}, lo[8], hi[8];
+        int cnt[8] = {0};
+        for (int x = 0; x < 8; ++x) { lo[x] = 1e30; hi[x] = -1e30; }
+        for (int b = 0; b < grid; ++b) {
+          const double t = (h[2 * b + 1] - first) * 0.01;
+          sum[b & 7] += t; ++cnt[b & 7];
+          lo[b & 7] = std::min(lo[b & 7], t); hi[b & 7] = std::max(hi[b & 7], t);
+        }
+        std::printf("    finish time by block%%8 (mean [min..max] us):");
+        for (int x = 0; x < 8; ++x) std::printf("  %d: %.1f [%.1f..%.1f]", x, sum[x] / cnt[x], lo[x], hi[x]);
+        std::printf("\n");
+      }
       std::fflush(stdout);
     }
-  // dynamic tail
-  unsigned* counters;
-  const int ncounters = launches + 8;
-  CHECK(hipMalloc(&counters, ncounters * 64));
-  const double fracs[] = {0.95, 0.9, 0.85, 0.75, 0.5, 0.0};
-  for (int bpc : {1, 2})
-    for (double f : fracs) {
-      const int grid = cus * bpc;
-      const size_t round = static_cast<size_t>(grid) * kBlock;
-      const size_t static_vec = static_cast<size_t>(nvec * f) / round * round;
-      CHECK(hipMemset(counters, 0, ncounters * 64));
-      for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL(probe_dyn_kernel<true>, dim3(grid), dim3(kBlock), 0, nullptr, pl, nvec, static_vec,
-                           counters + 16 * (launches + i % 8), out, clocks);
+  // Is the slow XCD the same from launch to launch?  8 consecutive launches, each with its own clock buffer.
+  {
+    unsigned long long* clk8;
+    const int grid = cus * 2;
+    CHECK(hipMalloc(&clk8, 8 * grid * 2 * sizeof(unsigned long long)));
+    for (int rep = 0; rep < 2; ++rep) {
+      for (int i = 0; i < 8; ++i)
+        hipLaunchKernelGGL((probe_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, nullptr, pl, nvec, out,
+                           clk8 + static_cast<size_t>(i) * grid * 2);
       CHECK(hipDeviceSynchronize());
-      CHECK(hipMemset(counters, 0, ncounters * 64));
-      CHECK(hipDeviceSynchronize());
-      CHECK(hipEventRecord(e0, nullptr));
-      for (int i = 0; i < launches; ++i)
-        hipLaunchKernelGGL(probe_dyn_kernel<true>, dim3(grid), dim3(kBlock), 0, nullptr, pl, nvec, static_vec,
-                           counters + 16 * i, out, clocks);
-      CHECK(hipEventRecord(e1, nullptr));
-      CHECK(hipEventSynchronize(e1));
-      CHECK(hipGetLastError());
-      float ms = 0;
-      CHECK(hipEventElapsedTime(&ms, e0, e1));
-      const double us = ms * 1e3 / launches;
-      h.resize(2 * grid);
-      CHECK(hipMemcpy(h.data(), clocks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      unsigned long long first = ~0ull, last = 0;
-      for (int b = 0; b < grid; ++b) { first = std::min(first, h[2 * b]); last = std::max(last, h[2 * b + 1]); }
-      std::vector<double> en(grid);
-      for (int b = 0; b < grid; ++b) en[b] = (last - h[2 * b + 1]) * 0.01;
-      std::sort(en.begin(), en.end());
-      std::printf("dyn tail static=%.2f   %2d blocks/CU  %7.1f us  %6.0f GB/s | in-kernel span %6.1f us; idle-before-end med %4.1f"
-                  " p90 %4.1f max %4.1f us\n",
-                  f, bpc, us, n * 8.0 * kPlanes / us * 1e-3, (last - first) * 0.01, en[grid / 2], en[grid * 9 / 10],
-                  en[grid - 1]);
-      std::fflush(stdout);
     }
+    std::vector<unsigned long long> hh(8 * grid * 2);
+    CHECK(hipMemcpy(hh.data(), clk8, hh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::printf("# 8 consecutive launches, 2 blocks/CU: mean finish time (us after the launch's first block start) by block%%8\n");
+    for (int i = 0; i < 8; ++i) {
+      const unsigned long long* c = hh.data() + static_cast<size_t>(i) * grid * 2;
+      unsigned long long first = ~0ull;
+      for (int b = 0; b < grid; ++b) first = std::min(first, c[2 * b]);
+      double sum[8] = {0};
+      for (int b = 0; b < grid; ++b) sum[b & 7] += (c[2 * b + 1] - first) * 0.01;
+      std::printf("launch %d:", i);
+      for (int x = 0; x < 8; ++x) std::printf(" %6.1f", sum[x] / (grid / 8));
+      std::printf("\n");
+    }
+    CHECK(hipFree(clk8));
+  }
   for (int k = 0; k < kPlanes; ++k) CHECK(hipFree(base[k]));
   return 0;
 }
