@@ -192,6 +192,7 @@ def test_full_size_properties(oracle, n, gen, mode, dm):
     d12 = c.d12 if dm == api.DEPTH_PER_MATCH else None
     with api.Problem(0) as p:
         p.upload(c.x1, c.x2, d12)
+        p.set_kernel(api.KERNEL_FACTORED)                  # whatever SBA_KERNEL says: the comparisons below are bitwise
         full = p.eval_pack(mode, c.rot_init, c.tran_init, depth_mode=dm)
         # the two kernels (factored moments vs explicit per-match Jacobian) agree at full size
         p.set_kernel(api.KERNEL_EXPLICIT)
