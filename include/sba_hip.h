@@ -317,6 +317,12 @@ int sba_batch_size(const sba_batch* b, int* num_pairs, int* blocks_per_pair);
  * SBA_DEPTH_PER_MATCH); packs: double[num_pairs][SBA_PACK_SIZE].                                          */
 int sba_batch_eval(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
                    const double* d1, const double* d2, double huber_delta, double* packs);
+/* `steps` host-synchronous batched steps in a C loop (bench / tuning): wall-clock mean per step and its split into
+ * host preparation of the per-pair R|t state, launch-to-result on the device, and host conversion of the packs.  */
+int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                         const double* d1, const double* d2, double huber_delta, int steps, double* packs,
+                         double* mean_step_ms, double* mean_prepare_ms, double* mean_device_ms,
+                         double* mean_convert_ms);
 /* rot / tran are updated in place per pair; summaries (sba_lm_summary[num_pairs]) and status
  * (int[num_pairs], SBA_OK or SBA_ERR_NUMERIC per pair) may be NULL.                                        */
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,

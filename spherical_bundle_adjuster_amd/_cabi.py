@@ -120,6 +120,8 @@ SIGNATURES = {
     "sba_batch_upload": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(C.c_size_t), C.c_int, C.c_int]),
     "sba_batch_size": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sba_batch_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp]),
+    "sba_batch_eval_timed": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, _dp,
+                                       _dp, _dp, _dp, _dp]),
     "sba_batch_solve": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(LmOptions),
                                   C.POINTER(LmSummary), C.POINTER(C.c_int)]),
     "sba_keypoints_to_sphere": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),

@@ -361,6 +361,20 @@ class Batch:
                                                        _dptr(packs)))
         return packs
 
+    def eval_timed(self, mode, rot, tran, steps, d1=None, d2=None, huber_delta=1.0, depth_mode=DEPTH_UNIFORM):
+        """`steps` host-synchronous batched steps in a C loop.  Returns (packs, dict of mean ms: step / prepare /
+        device / convert)."""
+        rot, rp = self._pp(rot, 3)
+        tran, tp = self._pp(tran, 3)
+        d1a, d1p = self._pp(d1, 1)
+        d2a, d2p = self._pp(d2, 1)
+        packs = np.zeros((self.num_pairs, cabi.PACK_SIZE))
+        ms = [C.c_double(0) for _ in range(4)]
+        cabi.check(self._lib, self._lib.sba_batch_eval_timed(
+            self._h, mode, depth_mode, rp, tp, d1p, d2p, huber_delta, steps, _dptr(packs),
+            *[C.cast(C.byref(m), C.POINTER(C.c_double)) for m in ms]))
+        return packs, dict(zip(("step_ms", "prepare_ms", "device_ms", "convert_ms"), (m.value for m in ms)))
+
     def solve(self, mode, rot, tran, d1=None, d2=None, depth_mode=DEPTH_UNIFORM, options: cabi.LmOptions | None = None):
         """Per-pair LM in lock-step.  Returns (rot (B,3), tran (B,3), [SolveSummary], status (B,))."""
         rot = _f64(rot).reshape(self.num_pairs, 3).copy()

@@ -3,6 +3,7 @@
 // evaluates every pair at its own R|t, and one host LmSolver per pair advances in lock-step off that launch.
 // Pairs are independent: across GPUs they shard without any collective.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +35,10 @@ struct sba_batch {
   double* partials = nullptr;
   int bpp = 1;                                // blocks per pair
   double* packs_dev = nullptr;
-  double* packs_host = nullptr;               // pinned
+  double* packs_host = nullptr;               // pinned + mapped: 24 doubles per pair, then the sequence word
+  double* packs_host_dev = nullptr;           // device-visible address of packs_host
+  unsigned long long seq = 0;                 // launches published so far
+  bool publish = true;                        // SBA_PUBLISH=0: D2H copy + stream synchronise instead
 };
 
 namespace {
@@ -49,7 +53,7 @@ int free_batch_data(sba_batch* b) {
   if (b->packs_dev) SBA_TRY_HIP(hipFree(b->packs_dev));
   if (b->packs_host) SBA_TRY_HIP(hipHostFree(b->packs_host));
   b->desc_dev = nullptr; b->params_dev = nullptr; b->params_host = nullptr; b->partials = nullptr;
-  b->packs_dev = nullptr; b->packs_host = nullptr;
+  b->packs_dev = nullptr; b->packs_host = nullptr; b->packs_host_dev = nullptr;
   b->uploaded = false; b->num_pairs = 0; b->n.clear(); b->first_vec.clear();
   return SBA_OK;
 }
@@ -69,22 +73,46 @@ int check_batch_args(const sba_batch* b, int mode, int depth_mode, const double*
 // One batched launch: pair g is evaluated at (rot[g], tran[g]) unless active[g] == 0.  packs_host then holds
 // the raw device packs (moment layout for the factored kernel).
 int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran, const double* d1,
-                 const double* d2, double huber_delta, const unsigned char* active) {
+                 const double* d2, double huber_delta, const unsigned char* active, double* prepare_ms = nullptr) {
   const int B = b->num_pairs;
+  const auto t_prep = std::chrono::steady_clock::now();
   for (int g = 0; g < B; ++g) {
     const bool on = !active || active[g];
     sba::make_sweep_params(on ? b->n[g] : 0, depth_mode, rot + 3 * g, tran + 3 * g, d1 ? d1[g] : 1.0,
                            d2 ? d2[g] : 1.0, huber_delta, &b->params_host[g]);
   }
+  if (prepare_ms)
+    *prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep).count();
   SBA_TRY_HIP(hipMemcpyAsync(b->params_dev, b->params_host, sizeof(sba::SweepParams) * B, hipMemcpyHostToDevice,
                              b->stream));
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
   pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  if (!b->publish) {
+    SBA_TRY_HIP(sba::launch_batch_sweep(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
+                                        b->desc_dev, B, b->bpp, b->partials, b->packs_dev, nullptr, 0, b->stream));
+    SBA_TRY_HIP(hipMemcpyAsync(b->packs_host, b->packs_dev, sizeof(double) * 24 * B, hipMemcpyDeviceToHost, b->stream));
+    SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    return SBA_OK;
+  }
+  // The finalize kernel stores the packs into mapped host memory, fences at system scope, then stores the sequence
+  // number: poll it.  A stream query every so often turns a device fault into an error instead of an endless spin.
+  const unsigned long long seq = ++b->seq;
   SBA_TRY_HIP(sba::launch_batch_sweep(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
-                                      b->desc_dev, B, b->bpp, b->partials, b->packs_dev, b->stream));
-  SBA_TRY_HIP(hipMemcpyAsync(b->packs_host, b->packs_dev, sizeof(double) * 24 * B, hipMemcpyDeviceToHost, b->stream));
-  SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+                                      b->desc_dev, B, b->bpp, b->partials, b->packs_dev, b->packs_host_dev, seq,
+                                      b->stream));
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B);
+  for (unsigned long spins = 0; *flag != seq; ++spins) {
+    if ((spins & 0xfff) == 0xfff) {
+      const hipError_t q = hipStreamQuery(b->stream);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return sba::set_error(SBA_ERR_HIP, "batched sweep failed on the device: %s", hipGetErrorString(q));
+      if (q == hipSuccess && *flag != seq)
+        return sba::set_error(SBA_ERR_HIP, "batched sweep finished without publishing its result");
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return SBA_OK;
 }
 
@@ -119,6 +147,7 @@ int sba_batch_create(sba_batch** out, int device, void* stream) {
   b->num_cus = prop.multiProcessorCount;
   if (const char* env = std::getenv("SBA_KERNEL"))
     if (std::strcmp(env, "explicit") == 0) b->kind = SBA_KERNEL_EXPLICIT;
+  if (const char* env = std::getenv("SBA_PUBLISH")) b->publish = std::strcmp(env, "0") != 0;
   if (stream) {
     b->stream = static_cast<hipStream_t>(stream);
   } else {
@@ -189,12 +218,12 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
     }
   if (num_pairs == 0) { b->uploaded = true; return SBA_OK; }
 
-  // blocks per pair: fill one resident wave of blocks over all pairs, never more than a pair can use
-  int occ = 1;
-  SBA_TRY_HIP(sba::batch_blocks_per_cu(SBA_MODE_RT, d12 ? SBA_DEPTH_PER_MATCH : SBA_DEPTH_UNIFORM, store, b->kind, true, &occ));
-  const size_t capacity = static_cast<size_t>(b->num_cus) * std::max(1, std::min(occ, 4));
+  // Blocks per pair: with at least one pair per CU, one block per pair (measured best at 256 pairs x 50k matches:
+  // 198 / 206 / 205 / 213 us per step for 1 / 2 / 3 / 4 blocks per pair); with fewer pairs, spread each pair over
+  // enough blocks to put two blocks on every CU like the single-problem sweep -- never more than a pair can use.
   const size_t need = (((max_n + ppt - 1) / ppt) + sba::kBlock - 1) / sba::kBlock;
-  b->bpp = static_cast<int>(std::max<size_t>(1, std::min<size_t>(std::max<size_t>(need, 1), std::max<size_t>(1, capacity / num_pairs))));
+  const size_t share = num_pairs >= b->num_cus ? 1 : static_cast<size_t>(2 * b->num_cus) / num_pairs;
+  b->bpp = static_cast<int>(std::max<size_t>(1, std::min(std::max<size_t>(need, 1), share)));
   if (const char* env = std::getenv("SBA_BATCH_BPP")) { const int v = std::atoi(env); if (v >= 1 && v <= 1024) b->bpp = v; }
 
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->desc_dev), sizeof(sba::PairDesc) * num_pairs));
@@ -203,7 +232,11 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->params_host), sizeof(sba::SweepParams) * num_pairs, hipHostMallocDefault));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->partials), sizeof(double) * sba::kRow * num_pairs * b->bpp));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->packs_dev), sizeof(double) * 24 * num_pairs));
-  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->packs_host), sizeof(double) * 24 * num_pairs, hipHostMallocDefault));
+  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->packs_host), sizeof(double) * (24 * num_pairs + 8),
+                            hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(b->packs_host, 0, sizeof(double) * (24 * num_pairs + 8));
+  SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->packs_host_dev), b->packs_host, 0));
+  b->seq = 0;
 
   // stage the AoS arrays whole, then re-lay each pair out at its plane offset
   const size_t base = offsets[0];
@@ -250,6 +283,38 @@ int sba_batch_eval(sba_batch* b, int mode, int depth_mode, const double* rot, co
   rc = batch_launch(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, nullptr);
   if (rc) return rc;
   for (int g = 0; g < b->num_pairs; ++g) convert_pack(b, mode, rot + 3 * g, b->packs_host + 24 * g, packs + 24 * g);
+  return SBA_OK;
+}
+
+int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                         const double* d1, const double* d2, double huber_delta, int steps, double* packs,
+                         double* mean_step_ms, double* mean_prepare_ms, double* mean_device_ms,
+                         double* mean_convert_ms) {
+  int rc = check_batch_args(b, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (steps <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "steps must be positive");
+  if (b->num_pairs > 0 && !packs) return sba::set_error(SBA_ERR_INVALID_ARG, "packs is null");
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  using clk = std::chrono::steady_clock;
+  double t_prep = 0, t_dev = 0, t_conv = 0;
+  const auto t_begin = clk::now();
+  for (int s = 0; s < steps && b->num_pairs > 0; ++s) {
+    double split[2] = {0, 0};
+    const auto t0 = clk::now();
+    rc = batch_launch(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, nullptr, split);
+    if (rc) return rc;
+    const auto t1 = clk::now();
+    for (int g = 0; g < b->num_pairs; ++g) convert_pack(b, mode, rot + 3 * g, b->packs_host + 24 * g, packs + 24 * g);
+    const auto t2 = clk::now();
+    t_prep += split[0];
+    t_dev += std::chrono::duration<double, std::milli>(t1 - t0).count() - split[0];
+    t_conv += std::chrono::duration<double, std::milli>(t2 - t1).count();
+  }
+  const double total = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+  if (mean_step_ms) *mean_step_ms = total / steps;
+  if (mean_prepare_ms) *mean_prepare_ms = t_prep / steps;
+  if (mean_device_ms) *mean_device_ms = t_dev / steps;
+  if (mean_convert_ms) *mean_convert_ms = t_conv / steps;
   return SBA_OK;
 }
 

@@ -90,7 +90,8 @@ struct PairDesc {
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
-                              double* partials, double* packs, hipStream_t stream);
+                              double* partials, double* packs, double* packs_host, unsigned long long seq,
+                              hipStream_t stream);
 
 // AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.
 hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void* px, void* py,

@@ -494,22 +494,37 @@ __global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const Sw
   }
 }
 
-// One wave per pair folds that pair's bpp rows (fixed order) into packs[pair][24].
-__global__ __launch_bounds__(64) void batch_finalize_kernel(const double* __restrict__ partials, int bpp,
-                                                            double* __restrict__ packs) {
-  const int pair = blockIdx.x, slot = threadIdx.x;
-  if (slot >= 24) return;
-  const double* rows = partials + static_cast<size_t>(pair) * bpp * kRow + slot;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = 0;
-  for (; b + 3 < bpp; b += 4) {
-    s0 += rows[static_cast<size_t>(b) * kRow];
-    s1 += rows[static_cast<size_t>(b + 1) * kRow];
-    s2 += rows[static_cast<size_t>(b + 2) * kRow];
-    s3 += rows[static_cast<size_t>(b + 3) * kRow];
+// ONE block folds every pair's bpp rows (fixed order) into packs[pair][24], on the device and -- when packs_host is
+// given -- in mapped pinned host memory, followed by a system-scope release and the sequence number in
+// packs_host[24 * num_pairs]: the host polls that word instead of queueing a D2H copy and synchronising the stream.
+__global__ __launch_bounds__(1024) void batch_finalize_kernel(const double* __restrict__ partials, int bpp,
+                                                              int num_pairs, double* __restrict__ packs,
+                                                              double* __restrict__ packs_host,
+                                                              unsigned long long seq) {
+  const int items = num_pairs * 24;
+  for (int it = threadIdx.x; it < items; it += 1024) {
+    const int pair = it / 24, slot = it - pair * 24;
+    const double* rows = partials + static_cast<size_t>(pair) * bpp * kRow + slot;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < bpp; b += 4) {
+      s0 += rows[static_cast<size_t>(b) * kRow];
+      s1 += rows[static_cast<size_t>(b + 1) * kRow];
+      s2 += rows[static_cast<size_t>(b + 2) * kRow];
+      s3 += rows[static_cast<size_t>(b + 3) * kRow];
+    }
+    for (; b < bpp; ++b) s0 += rows[static_cast<size_t>(b) * kRow];
+    const double tot = (s0 + s1) + (s2 + s3);
+    packs[it] = tot;
+    if (packs_host) packs_host[it] = tot;
   }
-  for (; b < bpp; ++b) s0 += rows[static_cast<size_t>(b) * kRow];
-  packs[static_cast<size_t>(pair) * 24 + slot] = (s0 + s1) + (s2 + s3);
+  if (!packs_host) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // every thread: its host stores before the barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + items), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- direct peer exchange over xGMI: the all-reduce of the 24-double pack without a collective library ----------
@@ -843,7 +858,8 @@ hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool lo
 
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
-                              double* partials, double* packs, hipStream_t stream) {
+                              double* partials, double* packs, double* packs_host, unsigned long long seq,
+                              hipStream_t stream) {
   if (num_pairs <= 0) return hipSuccess;
   BatchFn fn = bpick(mode, depth, store, kind, loss);
   if (!fn) return hipErrorInvalidValue;
@@ -851,7 +867,8 @@ hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool los
                      bpp, partials);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(batch_finalize_kernel, dim3(num_pairs), dim3(64), 0, stream, partials, bpp, packs);
+  hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
+                     packs_host, seq);
   return hipGetLastError();
 }
 
