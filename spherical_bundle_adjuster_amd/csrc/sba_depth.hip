@@ -43,13 +43,32 @@ template <> struct Pair<float> {
     out[0] = q.x; out[1] = q.y;
   }
 };
-__device__ __forceinline__ void load_pair_f64(const double* plane, size_t pair, double out[2]) {
-  const double2 q = reinterpret_cast<const double2*>(plane)[pair];
-  out[0] = q.x; out[1] = q.y;
-}
 __device__ __forceinline__ void store_pair_f64(double* plane, size_t pair, double a, double b) {
   reinterpret_cast<double2*>(plane)[pair] = make_double2(a, b);
 }
+
+__device__ __forceinline__ void store_pair_stream(double* plane, size_t pair, double a, double b) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const double2 q = make_double2(a, b);
+  __builtin_nontemporal_store(*reinterpret_cast<const f4*>(&q), reinterpret_cast<f4*>(plane) + pair);
+}
+
+// Everything one lane reads for its two matches of one grid-stride step.  Loaded one step ahead of its use (register
+// double buffer, like the sweep kernel): the ~300 VALU instructions per match (two exp at the current depths, two at
+// the candidate, one reciprocal) then run under the next step's loads instead of after them.
+template <typename ST>
+struct DepthRegs {
+  double X[2], Y[2], Z[2], U[2], V[2], W[2], A[2], B[2], S1[2], S2[2], DG1[2], DG2[2];
+  __device__ __forceinline__ void load(const Planes& pl, const double* d1, const double* d2, const double* sc1,
+                                       const double* sc2, const double* dg1, const double* dg2, bool load_scale,
+                                       bool load_diag, size_t pr) {
+    Pair<ST>::load(pl.x1[0], pr, X); Pair<ST>::load(pl.x1[1], pr, Y); Pair<ST>::load(pl.x1[2], pr, Z);
+    Pair<ST>::load(pl.x2[0], pr, U); Pair<ST>::load(pl.x2[1], pr, V); Pair<ST>::load(pl.x2[2], pr, W);
+    Pair<double>::load(d1, pr, A); Pair<double>::load(d2, pr, B);
+    if (load_scale) { Pair<double>::load(sc1, pr, S1); Pair<double>::load(sc2, pr, S2); }
+    if (load_diag) { Pair<double>::load(dg1, pr, DG1); Pair<double>::load(dg2, pr, DG2); }
+  }
+};
 
 template <typename ST>
 __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
@@ -61,19 +80,20 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
   __shared__ double red[4][8];
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
+  const bool load_scale = !P.first_iteration, load_diag = P.reuse_diagonal != 0;
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gmax = 0;
-  for (size_t pr = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; pr < npairs; pr += stride) {
-    double X[2], Y[2], Z[2], U[2], V[2], W[2], A[2], B[2], S1[2], S2[2], DG1[2], DG2[2];
-    Pair<ST>::load(pl.x1[0], pr, X); Pair<ST>::load(pl.x1[1], pr, Y); Pair<ST>::load(pl.x1[2], pr, Z);
-    Pair<ST>::load(pl.x2[0], pr, U); Pair<ST>::load(pl.x2[1], pr, V); Pair<ST>::load(pl.x2[2], pr, W);
-    load_pair_f64(d1, pr, A); load_pair_f64(d2, pr, B);
-    if (!P.first_iteration) { load_pair_f64(sc1, pr, S1); load_pair_f64(sc2, pr, S2); }
-    if (P.reuse_diagonal) { load_pair_f64(dg1, pr, DG1); load_pair_f64(dg2, pr, DG2); }
+  size_t pr = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  DepthRegs<ST> cur, nxt;
+  if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, dg1, dg2, load_scale, load_diag, pr);
+  while (pr < npairs) {
+    const size_t pn = pr + stride;
+    if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, dg1, dg2, load_scale, load_diag, pn);
     double NA[2], NB[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool valid = 2 * pr + h < P.n;
-      const double x = X[h], y = Y[h], z = Z[h], u = U[h], v = V[h], w = W[h], a = A[h], b = B[h];
+      const double x = cur.X[h], y = cur.Y[h], z = cur.Z[h], u = cur.U[h], v = cur.V[h], w = cur.W[h];
+      const double a = cur.A[h], b = cur.B[h];
       // q = R x1 ; e = b x2 - a q + t                                                   (.cpp:1008-1027)
       const double q0 = P.R[0] * x + P.R[1] * y + P.R[2] * z;
       const double q1 = P.R[3] * x + P.R[4] * y + P.R[5] * z;
@@ -90,22 +110,23 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
       if (P.first_iteration) {
         s1 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h11)) : 1.0;
         s2 = P.jacobi_scaling ? 1.0 / (1.0 + sqrt(h22)) : 1.0;
-        S1[h] = s1; S2[h] = s2;
+        cur.S1[h] = s1; cur.S2[h] = s2;
       } else {
-        s1 = S1[h]; s2 = S2[h];
+        s1 = cur.S1[h]; s2 = cur.S2[h];
       }
       const double H11 = s1 * h11 * s1, H12 = s1 * h12 * s2, H22 = s2 * h22 * s2, G1 = s1 * g1, G2 = s2 * g2;
       double D1, D2;
       if (P.reuse_diagonal) {
-        D1 = DG1[h]; D2 = DG2[h];
+        D1 = cur.DG1[h]; D2 = cur.DG2[h];
       } else {
         D1 = fmin(fmax(H11, P.min_diagonal), P.max_diagonal);
         D2 = fmin(fmax(H22, P.min_diagonal), P.max_diagonal);
-        DG1[h] = D1; DG2[h] = D2;
+        cur.DG1[h] = D1; cur.DG2[h] = D2;
       }
-      const double A11 = H11 + D1 / P.radius, A22 = H22 + D2 / P.radius, A12 = H12;
-      const double det = A11 * A22 - A12 * A12;
-      const double y1 = (-G1 * A22 + G2 * A12) / det, y2 = (-G2 * A11 + G1 * A12) / det;
+      // damped 2x2 system (H + D / radius) y = -G; 1 / radius comes from the host, 1 / det is formed once
+      const double A11 = __builtin_fma(D1, P.inv_radius, H11), A22 = __builtin_fma(D2, P.inv_radius, H22), A12 = H12;
+      const double inv_det = 1.0 / (A11 * A22 - A12 * A12);
+      const double y1 = (G2 * A12 - G1 * A22) * inv_det, y2 = (G1 * A12 - G2 * A11) * inv_det;
       const double na = fmax(a + s1 * y1, 0.0), nb = fmax(b + s2 * y2, 0.0);   // Plus + projection onto d >= 0
       NA[h] = na; NB[h] = nb;
       const double f0 = nb * u - na * q0 + P.t[0], f1 = nb * v - na * q1 + P.t[1], f2 = nb * w - na * q2 + P.t[2];
@@ -122,9 +143,11 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
         NA[h] = 0.0; NB[h] = 0.0;   // keep the padding zero
       }
     }
-    store_pair_f64(c1, pr, NA[0], NA[1]); store_pair_f64(c2, pr, NB[0], NB[1]);
-    if (P.first_iteration) { store_pair_f64(sc1, pr, S1[0], S1[1]); store_pair_f64(sc2, pr, S2[0], S2[1]); }
-    if (!P.reuse_diagonal) { store_pair_f64(dg1, pr, DG1[0], DG1[1]); store_pair_f64(dg2, pr, DG2[0], DG2[1]); }
+    store_pair_stream(c1, pr, NA[0], NA[1]); store_pair_stream(c2, pr, NB[0], NB[1]);
+    if (P.first_iteration) { store_pair_f64(sc1, pr, cur.S1[0], cur.S1[1]); store_pair_f64(sc2, pr, cur.S2[0], cur.S2[1]); }
+    if (!P.reuse_diagonal) { store_pair_f64(dg1, pr, cur.DG1[0], cur.DG1[1]); store_pair_f64(dg2, pr, cur.DG2[0], cur.DG2[1]); }
+    cur = nxt;
+    pr = pn;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double r[6] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),
@@ -140,31 +163,56 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
 }
 
 // [nblocks][8] -> out[8]: sums of slots 0..4 and the max of slot 5, in a fixed order.
-__global__ __launch_bounds__(256) void depth_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                             double* __restrict__ out) {
-  __shared__ double part[32][8];
-  const int slot = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  double s = 0.0;
-  if (slot < 6)
-    for (int b = grp; b < nblocks; b += 32) {
-      const double v = partials[static_cast<size_t>(b) * 8 + slot];
-      s = slot == 5 ? fmax(s, v) : s + v;
-    }
-  part[grp][slot] = s;
+// With host_out (mapped pinned memory) the six results are also published to the host: stores, system-scope release,
+// then the sequence number in host_out[24] -- the host polls that word (same protocol as finalize_kernel).
+__global__ __launch_bounds__(384) void depth_finalize_kernel(const double* __restrict__ partials, int nblocks,
+                                                             double* __restrict__ out, double* __restrict__ host_out,
+                                                             unsigned long long seq) {
+  // One wave per result: lane l folds rows l, l+64, ... (four independent loads in flight), then a butterfly over the
+  // wave.  The rows were just written by other CUs, so the length of this kernel is load round trips, not arithmetic.
+  __shared__ double res[8];
+  const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool is_max = slot == 5;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int b = lane;
+  for (; b + 192 < nblocks; b += 256) {
+    const double a0 = partials[static_cast<size_t>(b) * 8 + slot], a1 = partials[static_cast<size_t>(b + 64) * 8 + slot];
+    const double a2 = partials[static_cast<size_t>(b + 128) * 8 + slot], a3 = partials[static_cast<size_t>(b + 192) * 8 + slot];
+    if (is_max) { v0 = fmax(v0, a0); v1 = fmax(v1, a1); v2 = fmax(v2, a2); v3 = fmax(v3, a3); }
+    else { v0 += a0; v1 += a1; v2 += a2; v3 += a3; }
+  }
+  for (; b < nblocks; b += 64) {
+    const double a0 = partials[static_cast<size_t>(b) * 8 + slot];
+    v0 = is_max ? fmax(v0, a0) : v0 + a0;
+  }
+  const double s = is_max ? wave_max(fmax(fmax(v0, v1), fmax(v2, v3))) : wave_sum((v0 + v1) + (v2 + v3));
+  if (lane == 0) res[slot] = s;
   __syncthreads();
   if (threadIdx.x < 6) {
-    double tot = part[0][threadIdx.x];
-    for (int g = 1; g < 32; ++g) tot = threadIdx.x == 5 ? fmax(tot, part[g][5]) : tot + part[g][threadIdx.x];
-    out[threadIdx.x] = tot;
+    out[threadIdx.x] = res[threadIdx.x];
+    if (host_out) host_out[threadIdx.x] = res[threadIdx.x];
+  }
+  if (host_out && threadIdx.x < 64) {     // wave 0 holds all six host stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + 24), seq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 }  // namespace
 
+hipError_t depth_blocks_per_cu(int store, int* blocks) {
+  const void* fn = store == 0 ? reinterpret_cast<const void*>(depth_step_kernel<double>)
+                              : reinterpret_cast<const void*>(depth_step_kernel<float>);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, 256, 0);
+}
+
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
-                             const DepthParams& prm, double* partials, int grid, double* out8,
-                             hipStream_t stream) {
+                             const DepthParams& prm, double* partials, int grid, double* out8, double* host_out,
+                             unsigned long long seq, hipStream_t stream) {
   if (grid > 0) {
     if (store == 0)
       hipLaunchKernelGGL((depth_step_kernel<double>), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1,
@@ -175,7 +223,7 @@ hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, cons
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(256), 0, stream, partials, grid, out8);
+  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(384), 0, stream, partials, grid, out8, host_out, seq);
   return hipGetLastError();
 }
 

@@ -107,7 +107,7 @@ struct DepthParams {
   double R[9];
   double t[3];
   double lambda, c;
-  double radius;
+  double radius, inv_radius;
   double min_diagonal, max_diagonal;
   int first_iteration;   // compute and store the Jacobi scaling
   int reuse_diagonal;    // previous step was rejected: keep the stored LM diagonal
@@ -117,10 +117,11 @@ struct DepthParams {
 };
 // out8: [0] cost at d, [1] model cost change, [2] cost at candidate, [3] |step|^2, [4] |d|^2, [5] projected
 // gradient max-norm at d.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.
+hipError_t depth_blocks_per_cu(int store, int* blocks);   // resident 256-thread blocks per CU of depth_step_kernel
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
-                             const DepthParams& prm, double* partials, int grid, double* out8,
-                             hipStream_t stream);
+                             const DepthParams& prm, double* partials, int grid, double* out8, double* host_out,
+                             unsigned long long seq, hipStream_t stream);
 
 // 8-point initial guess, device part (.cpp:53-68): A^T A of the kron(left, right) rows for 64 interleaved groups.
 // groups_dev: [64][45]; partials: [grid][45][64] scratch.

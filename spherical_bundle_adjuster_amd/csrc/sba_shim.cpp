@@ -132,6 +132,7 @@ struct sba_problem {
                                // more waves only add rows to fold (profiles/r01_tune_caps.log)
   int kind = SBA_KERNEL_FACTORED;
   int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
+  int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
   int last_mode = 0;
 
@@ -872,7 +873,16 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   double* work = work_buf.as<double>();
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
          *dg2 = work + 5 * elems;
-  const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256, static_cast<size_t>(p->num_cus) * 8));
+  // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
+  int& occ = p->depth_occ[p->store];
+  if (occ == 0) {
+    SBA_HIP_TRY(sba::depth_blocks_per_cu(p->store, &occ));
+    occ = std::max(1, occ);
+  }
+  int cap = 8;
+  if (const char* env = std::getenv("SBA_DEPTH_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) cap = v; }
+  const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256,
+                                                     static_cast<size_t>(p->num_cus) * std::max(1, std::min(occ, cap))));
   SBA_HIP_TRY(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
   SBA_HIP_TRY(out_buf.alloc(8 * sizeof(double)));
   double *partials = partials_buf.as<double>(), *out_dev = out_buf.as<double>();
@@ -895,11 +905,29 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   int invalid = 0, rc_final = SBA_OK;
   double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto step = [&]() -> int {   // one device pass at the current depths
-    prm.radius = radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
-    SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
-                                       out_dev, p->stream));
-    SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
+    if (p->publish) {
+      // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
+      const unsigned long long seq = ++p->seq;
+      SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                         out_dev, p->pack_host_dev, seq, p->stream));
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24);
+      for (unsigned long spins = 0; *flag != seq; ++spins) {
+        if ((spins & 0xfff) == 0xfff) {
+          const hipError_t q = hipStreamQuery(p->stream);
+          if (q != hipSuccess && q != hipErrorNotReady)
+            return fail(SBA_ERR_HIP, "d-only pass failed on the device: %s", hipGetErrorString(q));
+          if (q == hipSuccess && *flag != seq) return fail(SBA_ERR_HIP, "d-only pass finished without publishing its result");
+        }
+        __builtin_ia32_pause();
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+      SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                         out_dev, nullptr, 0, p->stream));
+      SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    }
     std::memcpy(out, p->pack_host, sizeof(out));
     sum->num_evaluations++;
     first = false;
