@@ -2,8 +2,8 @@
 // exactly once with the sweep kernel's access pattern and does (almost) no arithmetic?  The answer is the ceiling the
 // sweep kernel is measured against in DESIGN.md section 7, next to the 8 TB/s datasheet figure.
 //
-//   build:  hipcc --offload-arch=gfx950 -O3 -o build/stream_probe tools/stream_probe.hip
-//   run:    build/stream_probe [n_matches=10000000] [launches=50]
+//   build:  make -C spherical_bundle_adjuster_amd/csrc      (-> csrc/build/stream_probe)
+//   run:    spherical_bundle_adjuster_amd/csrc/build/stream_probe [n_matches=10000000] [launches=50]   (on the GPU box)
 //
 // (A dynamically balanced tail -- 64-vector chunks handed out by one agent-scope atomic counter -- was measured with
 // an earlier version of this probe: ~10 ns per same-address ticket, 907 us for a fully dynamic 10M launch; dropped.)
