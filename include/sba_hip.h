@@ -278,6 +278,10 @@ int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok);
 int sba_problem_peer_disable(sba_problem* p);
 /* Option B: user hook (e.g. torch.distributed.all_reduce on a tensor aliasing device_buf).  */
 int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
+/* Which shard of the correspondences this problem holds.  sba_problem_comm_init_rank and sba_problem_peer_export set
+ * it themselves; with the user hook call it explicitly before sba_problem_solve_depths, whose gradient max-norm
+ * travels through the SUM all-reduce as one pack slot per shard (hence at most 16 shards).                         */
+int sba_problem_set_shard(sba_problem* p, int rank, int nranks);
 /* Device address of the 24-double result pack the hook / RCCL operates on (a sum over
  * correspondences in either kernel's layout, so summing it across shards is exact).            */
 int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);

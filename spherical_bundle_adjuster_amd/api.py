@@ -268,6 +268,10 @@ class Problem:
     def peer_disable(self) -> None:
         cabi.check(self._lib, self._lib.sba_problem_peer_disable(self._h))
 
+    def set_shard(self, rank: int, nranks: int) -> None:
+        """Which shard of the correspondences this problem holds (needed by the d-only stage over the user hook)."""
+        cabi.check(self._lib, self._lib.sba_problem_set_shard(self._h, rank, nranks))
+
     def set_allreduce(self, fn) -> None:
         """fn(device_ptr: int, count: int, stream: int) -> int (0 = ok), or None to clear."""
         if fn is None:

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
 // then the sequence number in host_out[24] -- the host polls that word (same protocol as finalize_kernel).
 __global__ __launch_bounds__(384) void depth_finalize_kernel(const double* __restrict__ partials, int nblocks,
                                                              double* __restrict__ out, double* __restrict__ host_out,
-                                                             unsigned long long seq) {
+                                                             unsigned long long seq, int gather_slot) {
   // One wave per result: lane l folds rows l, l+64, ... (four independent loads in flight), then a butterfly over the
   // wave.  The rows were just written by other CUs, so the length of this kernel is load round trips, not arithmetic.
   __shared__ double res[8];
@@ -188,6 +188,14 @@ __global__ __launch_bounds__(384) void depth_finalize_kernel(const double* __res
   const double s = is_max ? wave_max(fmax(fmax(v0, v1), fmax(v2, v3))) : wave_sum((v0 + v1) + (v2 + v3));
   if (lane == 0) res[slot] = s;
   __syncthreads();
+  if (gather_slot >= 0) {
+    // Sharded problem: `out` is the 24-double pack a SUM all-reduce follows on.  Slots 0..4 carry the five sums; the
+    // maximum cannot be summed, so every rank deposits its own in slot 8 + rank (zeros elsewhere) -- after the
+    // all-reduce every rank holds all of them and takes the maximum on the host.
+    if (threadIdx.x < 24)
+      out[threadIdx.x] = threadIdx.x < 5 ? res[threadIdx.x] : (static_cast<int>(threadIdx.x) == 8 + gather_slot ? res[5] : 0.0);
+    return;
+  }
   if (threadIdx.x < 6) {
     out[threadIdx.x] = res[threadIdx.x];
     if (host_out) host_out[threadIdx.x] = res[threadIdx.x];
@@ -212,7 +220,7 @@ hipError_t depth_blocks_per_cu(int store, int* blocks) {
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
                              const DepthParams& prm, double* partials, int grid, double* out8, double* host_out,
-                             unsigned long long seq, hipStream_t stream) {
+                             unsigned long long seq, int gather_slot, hipStream_t stream) {
   if (grid > 0) {
     if (store == 0)
       hipLaunchKernelGGL((depth_step_kernel<double>), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1,
@@ -223,7 +231,8 @@ hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, cons
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(384), 0, stream, partials, grid, out8, host_out, seq);
+  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(384), 0, stream, partials, grid, out8, host_out, seq,
+                     gather_slot);
   return hipGetLastError();
 }
 

@@ -115,13 +115,15 @@ struct DepthParams {
   int pad_;
   unsigned long long n;
 };
+// gather_slot >= 0 (sharded problem): out8 is a 24-double pack for a SUM all-reduce, sums in [0..4], this rank's
+// gradient max-norm in [8 + gather_slot], zeros elsewhere; nothing is published to the host.
 // out8: [0] cost at d, [1] model cost change, [2] cost at candidate, [3] |step|^2, [4] |d|^2, [5] projected
 // gradient max-norm at d.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.
 hipError_t depth_blocks_per_cu(int store, int* blocks);   // resident 256-thread blocks per CU of depth_step_kernel
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
                              const DepthParams& prm, double* partials, int grid, double* out8, double* host_out,
-                             unsigned long long seq, hipStream_t stream);
+                             unsigned long long seq, int gather_slot, hipStream_t stream);
 
 // 8-point initial guess, device part (.cpp:53-68): A^T A of the kron(left, right) rows for 64 interleaved groups.
 // groups_dev: [64][45]; partials: [grid][45][64] scratch.

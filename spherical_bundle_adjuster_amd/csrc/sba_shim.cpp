@@ -172,6 +172,7 @@ struct sba_problem {
   void* hook_user = nullptr;
   void* comm = nullptr;        // ncclComm_t
   int nranks = 1;
+  int shard_rank = 0, shard_count = 1;   // which shard of the correspondences this problem holds (d-only stage)
 };
 
 namespace {
@@ -259,6 +260,36 @@ void make_frame(sba_problem* p, int mode, const double rot[3]) {
 }
 
 // Enqueue one sweep + finalize (+ all-reduce) on the problem's stream; pack_dev holds the result.
+// SUM all-reduce of the 24-double pack in p->pack_dev over the attached transport (RCCL or the user hook), then the
+// one-wave publish kernel hands the result to the host like the single-GPU path does itself.
+int allreduce_pack(sba_problem* p) {
+  if (p->peer_ready) {   // direct peer stores + rank-ordered local sum; the exchanging wave publishes to the host
+    p->published = p->publish;
+    if (p->publish) ++p->seq;
+    SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev,
+                                          p->publish ? p->pack_host_dev : nullptr, p->seq, p->peer_spin_limit,
+                                          p->stream));
+    return SBA_OK;
+  }
+  if (p->comm) {
+    Rccl& r = rccl();
+    const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
+                               p->comm, p->stream);
+    if (rc != 0)
+      return fail(SBA_ERR_COMM, "ncclAllReduce failed: %s",
+                  r.GetErrorString ? r.GetErrorString(rc) : "?");
+  } else if (p->hook) {
+    const int rc = p->hook(p->pack_dev, SBA_PACK_SIZE, p->stream, p->hook_user);
+    if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
+  }
+  p->published = false;
+  if (p->publish) {
+    SBA_HIP_TRY(sba::launch_publish(p->pack_dev, p->pack_host_dev, ++p->seq, p->stream));
+    p->published = true;
+  }
+  return SBA_OK;
+}
+
 int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepParams& prm) {
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) {
@@ -305,22 +336,7 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   if (!fused)
     SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
                                      nullptr, 0, 0, p->stream));
-  if (p->comm) {
-    Rccl& r = rccl();
-    const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
-                               p->comm, p->stream);
-    if (rc != 0)
-      return fail(SBA_ERR_COMM, "ncclAllReduce failed: %s",
-                  r.GetErrorString ? r.GetErrorString(rc) : "?");
-  } else if (p->hook) {
-    const int rc = p->hook(p->pack_dev, SBA_PACK_SIZE, p->stream, p->hook_user);
-    if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
-  }
-  if (collective && p->publish) {
-    // the all-reduced pack is published by a one-wave kernel (host polls), like the single-GPU path does itself
-    SBA_HIP_TRY(sba::launch_publish(p->pack_dev, p->pack_host_dev, ++p->seq, p->stream));
-    p->published = true;
-  }
+  if (collective) return allreduce_pack(p);
   return SBA_OK;
 }
 
@@ -734,6 +750,8 @@ int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char 
   if (p->comm) r.CommDestroy(p->comm);
   p->comm = comm;
   p->nranks = nranks;
+  p->shard_rank = rank;
+  p->shard_count = nranks;
   return SBA_OK;
 }
 
@@ -768,6 +786,8 @@ int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SB
   std::memcpy(handle, &h, SBA_PEER_HANDLE_BYTES);
   p->peers.nranks = nranks;
   p->peers.rank = rank;
+  p->shard_rank = rank;
+  p->shard_count = nranks;
   return SBA_OK;
 }
 
@@ -845,6 +865,14 @@ int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user) {
   return SBA_OK;
 }
 
+int sba_problem_set_shard(sba_problem* p, int rank, int nranks) {
+  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SBA_ERR_INVALID_ARG, "bad shard %d/%d", rank, nranks);
+  p->shard_rank = rank;
+  p->shard_count = nranks;
+  return SBA_OK;
+}
+
 int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr) {
   if (!p || !dev_ptr) return fail(SBA_ERR_INVALID_ARG, "null argument");
   *dev_ptr = p->pack_dev;
@@ -857,7 +885,12 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   if (!p || !rot || !tran) return fail(SBA_ERR_INVALID_ARG, "null argument");
   if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   if (!p->has_d12 && p->n > 0) return fail(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
-  if (p->comm || p->hook) return fail(SBA_ERR_UNSUPPORTED, "d-only stage is single-GPU in this release");
+  // Sharded problem: the six global reductions of every pass are all-reduced over the attached transport (the
+  // maximum travels as one slot per rank, so at most 16 shards), and every rank replays the same step logic.
+  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
+  if (collective && (p->shard_count < 1 || p->shard_count > 16 || p->shard_rank < 0 || p->shard_rank >= p->shard_count))
+    return fail(SBA_ERR_UNSUPPORTED, "d-only stage over a transport needs 1..16 shards (sba_problem_set_shard); have %d/%d",
+                p->shard_rank, p->shard_count);
   SBA_HIP_TRY(hipSetDevice(p->device));
   sba_lm_options o;
   if (opt) o = *opt; else sba::lm_default_options(&o);
@@ -906,11 +939,26 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto step = [&]() -> int {   // one device pass at the current depths
     prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
+    if (collective) {
+      SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                         p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
+      int rc = allreduce_pack(p);
+      if (rc) return rc;
+      double raw[SBA_PACK_SIZE];
+      rc = fetch_pack_raw(p, raw);
+      if (rc) return rc;
+      for (int k = 0; k < 5; ++k) out[k] = raw[k];
+      out[5] = 0.0;
+      for (int r = 0; r < p->shard_count; ++r) out[5] = std::max(out[5], raw[8 + r]);
+      sum->num_evaluations++;
+      first = false;
+      return SBA_OK;
+    }
     if (p->publish) {
       // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
       const unsigned long long seq = ++p->seq;
       SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
-                                         out_dev, p->pack_host_dev, seq, p->stream));
+                                         out_dev, p->pack_host_dev, seq, -1, p->stream));
       volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24);
       for (unsigned long spins = 0; *flag != seq; ++spins) {
         if ((spins & 0xfff) == 0xfff) {
@@ -924,7 +972,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {
       SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
-                                         out_dev, nullptr, 0, p->stream));
+                                         out_dev, nullptr, 0, -1, p->stream));
       SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       SBA_HIP_TRY(hipStreamSynchronize(p->stream));
     }

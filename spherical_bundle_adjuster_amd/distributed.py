@@ -123,5 +123,6 @@ def _install_hook(problem: api.Problem, torch, dist) -> str:
         dist.all_reduce(pack)
         return 0
     problem.set_allreduce(hook)
+    problem.set_shard(dist.get_rank(), dist.get_world_size())
     problem._torch_pack_alias = pack
     return "torch-hook"

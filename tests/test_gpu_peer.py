@@ -35,12 +35,14 @@ def _worker(rank, world, port, q):
             packs.append(p.eval_steps(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH, steps=20)[0])
             r, t, s = p.solve(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH)
             tr, _, _ = p.solve(A.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
+            # d-only stage on the sharded problem: six global reductions exchanged per pass, identical step logic
+            d, sd = p.solve_depths(c.rot_true, c.tran_true)
             dist.barrier()
             p.peer_disable()
-        q.put((rank, used, packs, r, t, s.num_iterations, tr))
+        q.put((rank, used, packs, r, t, s.num_iterations, tr, (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost)))
     except Exception as e:      # surface the failure in the parent instead of a silent timeout
         import traceback
-        q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None))
+        q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None, None))
     finally:
         dist.destroy_process_group()
 
@@ -65,13 +67,19 @@ def test_peer_exchange_processes_on_one_gpu(world):
         single = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
         r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
         tr1, _, _ = p.solve(api.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
-    for rank, used, packs, r, t, iters, tr in res:
+        d1, sd1 = p.solve_depths(c.rot_true, c.tran_true)
+    for rank, used, packs, r, t, iters, tr, depth in res:
         for pk in packs:
             assert np.array_equal(pk, res[0][2][0])                         # bit-identical on every rank, every repeat
         assert np.abs(packs[0] - single).max() <= REL_TOL_F64 * np.abs(single).max()
         assert np.array_equal(r, res[0][3]) and np.array_equal(t, res[0][4])   # lock-step LM
         assert iters == s1.num_iterations and np.abs(r - r1).max() <= 1e-11 and np.abs(t - t1).max() <= 1e-11
         assert np.abs(tr - tr1).max() <= 1e-11
+        lo, hi, d, d_iters, d_term, d_cost = depth
+        assert (d_iters, d_term) == (sd1.num_iterations, sd1.termination)
+        assert d_cost == res[0][7][5]                                            # the same reduced numbers on every rank
+        assert abs(d_cost - sd1.final_cost) <= 1e-12 * sd1.final_cost
+        assert np.abs(d - d1[lo:hi]).max() <= 1e-9
 
 
 def test_bench_multi_rank_rehearsal(tmp_path):

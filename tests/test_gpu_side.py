@@ -189,11 +189,17 @@ def test_distributed_attach_one_rank_process_group(oracle):
         with api.Problem(0) as p:
             p.upload(c.x1, c.x2, c.d12)
             base = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            d_plain, sd_plain = p.solve_depths(c.rot_true, c.tran_true)          # no transport attached
+            p.set_depths(c.d12)
             assert distributed.attach(p) == "none"
             assert distributed.attach(p, prefer_native=True, force=True) == "rccl-native"
             assert np.array_equal(p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH), base)
             r, t, s_ = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
             assert s_.termination.startswith("CONVERGENCE")
+            # the d-only stage over the transport (sums all-reduced, the max gathered through one slot per rank)
+            d_rccl, sd_rccl = p.solve_depths(c.rot_true, c.tran_true)
+            assert (sd_rccl.num_iterations, sd_rccl.termination) == (sd_plain.num_iterations, sd_plain.termination)
+            assert np.abs(d_rccl - d_plain).max() <= 1e-12
         with api.Problem(0, stream=torch.cuda.current_stream().cuda_stream) as p:
             p.upload(c.x1, c.x2, c.d12)
             assert distributed.attach(p, prefer_native=False, force=True) == "torch-hook"
@@ -206,6 +212,9 @@ def test_distributed_attach_one_rank_process_group(oracle):
             assert np.array_equal(p._torch_pack_alias.cpu().numpy(), got)
             r2, t2, s2 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
             assert np.abs(r2 - r).max() <= 1e-12 and s2.num_iterations == s_.num_iterations
+            d_hook, sd_hook = p.solve_depths(c.rot_true, c.tran_true)
+            assert (sd_hook.num_iterations, sd_hook.termination) == (sd_plain.num_iterations, sd_plain.termination)
+            assert np.abs(d_hook - d_plain).max() <= 1e-12
     finally:
         dist.destroy_process_group()
 
