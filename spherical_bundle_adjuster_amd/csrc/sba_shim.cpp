@@ -290,6 +290,31 @@ int allreduce_pack(sba_problem* p) {
   return SBA_OK;
 }
 
+// SUM all-reduce of `count` doubles at `dev` (count a multiple of 24) over the attached transport, in stream order.
+// Over the peer transport the buffer travels as count / 24 back-to-back exchanges of the 24-double inbox slots; the
+// last one publishes to the host so that a timeout shows in word 25 of the host pack (checked by the caller).
+int allreduce_buffer(sba_problem* p, double* dev, size_t count) {
+  if (p->peer_ready) {
+    if (count % SBA_PACK_SIZE != 0) return fail(SBA_ERR_INVALID_ARG, "peer all-reduce needs a multiple of 24 doubles");
+    for (size_t off = 0; off < count; off += SBA_PACK_SIZE) {
+      const bool last = off + SBA_PACK_SIZE >= count;
+      SBA_HIP_TRY(sba::launch_peer_exchange(dev + off, p->peers, ++p->xseq, dev + off,
+                                            last ? p->pack_host_dev : nullptr, last ? ++p->seq : 0,
+                                            p->peer_spin_limit, p->stream));
+    }
+    return SBA_OK;
+  }
+  if (p->comm) {
+    Rccl& r = rccl();
+    const int rc = r.AllReduce(dev, dev, count, kNcclFloat64, kNcclSum, p->comm, p->stream);
+    if (rc != 0) return fail(SBA_ERR_COMM, "ncclAllReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
+  } else if (p->hook) {
+    const int rc = p->hook(dev, count, p->stream, p->hook_user);
+    if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
+  }
+  return SBA_OK;
+}
+
 int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepParams& prm) {
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) {
@@ -1055,8 +1080,17 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
   for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
   pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
   SBA_HIP_TRY(sba::launch_epipolar_moments(p->store, pl, p->n, partials, grid, groups_dev, p->stream));
+  // Sharded problem: group g of the whole problem is the union of every shard's group g, so the 64 x 45 sums are
+  // all-reduced and every rank derives the same initial guess from the same numbers.
+  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
+  if (collective) {
+    const int rc = allreduce_buffer(p, groups_dev, gsz);
+    if (rc) return rc;
+  }
   SBA_HIP_TRY(hipMemcpyAsync(groups, groups_dev, gsz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  if (collective && p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
+    return fail(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's group moments");
   return SBA_OK;
 }
 

@@ -117,10 +117,20 @@ def attach(problem: api.Problem, transport: str = "auto", force: bool = False, p
 
 def _install_hook(problem: api.Problem, torch, dist) -> str:
     dev = torch.device("cuda", torch.cuda.current_device())
-    pack = torch.as_tensor(_DevicePack(problem.pack_device_ptr, 24), device=dev)
+    pack_ptr = problem.pack_device_ptr
+    pack = torch.as_tensor(_DevicePack(pack_ptr, 24), device=dev)
+    aliases = {(pack_ptr, 24): pack}
 
-    def hook(_ptr, _count, _stream):
-        dist.all_reduce(pack)
+    def hook(ptr, count, _stream):
+        # the 24-double pack on every sweep; other device buffers (the 64 x 45 group moments of the initial guess)
+        # get their own alias the first time they appear
+        t = aliases.get((ptr, count))
+        if t is None:
+            t = aliases[(ptr, count)] = torch.as_tensor(_DevicePack(ptr, count), device=dev)
+            if len(aliases) > 64:          # scratch buffers come and go: keep the table small
+                for k in [k for k in aliases if k != (pack_ptr, 24) and k != (ptr, count)]:
+                    del aliases[k]
+        dist.all_reduce(t)
         return 0
     problem.set_allreduce(hook)
     problem.set_shard(dist.get_rank(), dist.get_world_size())

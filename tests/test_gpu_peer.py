@@ -37,14 +37,26 @@ def _worker(rank, world, port, q):
             tr, _, _ = p.solve(A.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
             # d-only stage on the sharded problem: six global reductions exchanged per pass, identical step logic
             d, sd = p.solve_depths(c.rot_true, c.tran_true)
+            # 8-point initial guess on the sharded problem: group moments all-reduced, same guess on every rank
+            gm = p.epipolar_moments()
+            eul, tg, ncand = p.initial_guess(80, 0.25, 5)
             dist.barrier()
             p.peer_disable()
-        q.put((rank, used, packs, r, t, s.num_iterations, tr, (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost)))
+        q.put((rank, used, packs, r, t, s.num_iterations, tr, (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost), (gm, eul, tg, ncand)))
     except Exception as e:      # surface the failure in the parent instead of a silent timeout
         import traceback
-        q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None, None))
+        q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None, None, None))
     finally:
         dist.destroy_process_group()
+
+
+def _shard_moments(c, world):
+    """Group moments of every shard, each computed by a plain single-process problem."""
+    for rank in range(world):
+        lo, hi = synthetic.shard_range(N, rank, world)
+        with api.Problem(0) as p:
+            p.upload(c.x1[lo:hi], c.x2[lo:hi], c.d12[lo:hi])
+            yield p.epipolar_moments()
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -68,7 +80,8 @@ def test_peer_exchange_processes_on_one_gpu(world):
         r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
         tr1, _, _ = p.solve(api.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
         d1, sd1 = p.solve_depths(c.rot_true, c.tran_true)
-    for rank, used, packs, r, t, iters, tr, depth in res:
+    total_moments = sum(m for m in _shard_moments(c, world))
+    for rank, used, packs, r, t, iters, tr, depth, guess in res:
         for pk in packs:
             assert np.array_equal(pk, res[0][2][0])                         # bit-identical on every rank, every repeat
         assert np.abs(packs[0] - single).max() <= REL_TOL_F64 * np.abs(single).max()
@@ -80,6 +93,10 @@ def test_peer_exchange_processes_on_one_gpu(world):
         assert d_cost == res[0][7][5]                                            # the same reduced numbers on every rank
         assert abs(d_cost - sd1.final_cost) <= 1e-12 * sd1.final_cost
         assert np.abs(d - d1[lo:hi]).max() <= 1e-9
+        gm, eul, tg, ncand = guess
+        assert np.array_equal(gm, res[0][8][0]) and np.array_equal(eul, res[0][8][1]) and np.array_equal(tg, res[0][8][2])
+        assert np.abs(gm - total_moments).max() <= 1e-12 * np.abs(total_moments).max()
+        assert ncand > 0
 
 
 def test_bench_multi_rank_rehearsal(tmp_path):

@@ -189,6 +189,7 @@ def test_distributed_attach_one_rank_process_group(oracle):
         with api.Problem(0) as p:
             p.upload(c.x1, c.x2, c.d12)
             base = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            gm_plain = p.epipolar_moments()
             d_plain, sd_plain = p.solve_depths(c.rot_true, c.tran_true)          # no transport attached
             p.set_depths(c.d12)
             assert distributed.attach(p) == "none"
@@ -200,6 +201,7 @@ def test_distributed_attach_one_rank_process_group(oracle):
             d_rccl, sd_rccl = p.solve_depths(c.rot_true, c.tran_true)
             assert (sd_rccl.num_iterations, sd_rccl.termination) == (sd_plain.num_iterations, sd_plain.termination)
             assert np.abs(d_rccl - d_plain).max() <= 1e-12
+            assert np.array_equal(p.epipolar_moments(), gm_plain)                # 64 x 45 group moments all-reduced
         with api.Problem(0, stream=torch.cuda.current_stream().cuda_stream) as p:
             p.upload(c.x1, c.x2, c.d12)
             assert distributed.attach(p, prefer_native=False, force=True) == "torch-hook"
@@ -215,6 +217,7 @@ def test_distributed_attach_one_rank_process_group(oracle):
             d_hook, sd_hook = p.solve_depths(c.rot_true, c.tran_true)
             assert (sd_hook.num_iterations, sd_hook.termination) == (sd_plain.num_iterations, sd_plain.termination)
             assert np.abs(d_hook - d_plain).max() <= 1e-12
+            assert np.array_equal(p.epipolar_moments(), gm_plain)                # the hook aliases that buffer too
     finally:
         dist.destroy_process_group()
 
