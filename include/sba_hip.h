@@ -252,8 +252,9 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
  * 3-vector and lambda*exp(-c*d1), lambda*exp(-c*d2); no loss; lower bound 0; the reference uses lambda = c = 1).
  * Needs per-match depths uploaded (they are the initial values, init_d) and updates them on the device, so a
  * following SBA_DEPTH_PER_MATCH sweep sees the refined depths.  d12_out (double[2n], may be NULL) receives
- * them in init_d layout.  opt NULL = defaults (huber_delta / tran_param are ignored).  Single-GPU in this
- * release: returns SBA_ERR_UNSUPPORTED when a communicator or all-reduce hook is installed.               */
+ * them in init_d layout.  opt NULL = defaults (huber_delta / tran_param are ignored).  With a transport
+ * attached (sharded problem) the six global reductions of every pass are all-reduced, all ranks take the
+ * same steps, and every rank receives its own shard's depths (at most 16 shards, see sba_problem_set_shard). */
 int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
                              double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary);
 
@@ -289,7 +290,8 @@ int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);
 /* ---- 8-point initial guess (eight_point_estimation / initial_guess, spherical_bundle_adjuster.cpp:47-181) ---- */
 /* Device part: one pass over the uploaded correspondences accumulating A^T A of the rows kron(left_i, right_i)
  * (.cpp:53-68) for 64 interleaved groups, group(i) = (i / 4) % 64.  groups: double[64][45] (upper triangle,
- * row-major a <= b).                                                                                         */
+ * row-major a <= b).  With a transport attached (sharded problem) the sums are all-reduced: every rank receives
+ * the moments of the whole problem (group g = the union of all shards' group g) and so derives the same guess.  */
 int sba_problem_epipolar_moments(sba_problem* p, double* groups);
 /* Host part (no device needed): `trials` trials (80 in the reference, .cpp:130), each on a random
  * `subset_fraction` (0.25, .cpp:133) of the groups: null vector of A (smallest eigenvector of A^T A), rank-2
