@@ -112,6 +112,7 @@ SIGNATURES = {
     "sba_problem_peer_connect": (C.c_int, [_vp, C.c_char_p]),
     "sba_problem_peer_selftest": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "sba_problem_peer_disable": (C.c_int, [_vp]),
+    "sba_set_host_threads": (C.c_int, [C.c_int]),
     "sba_problem_set_shard": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sba_problem_set_allreduce": (C.c_int, [_vp, ALLREDUCE_FN, _vp]),
     "sba_problem_pack_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),

@@ -393,6 +393,12 @@ class Batch:
         return rot, tran, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
 
 
+def set_host_threads(n: int) -> None:
+    """Host threads for the host-side trial loop of the initial guess (reference: set_omp).  0 = auto."""
+    lib = cabi.load_library()
+    cabi.check(lib, lib.sba_set_host_threads(n))
+
+
 def initial_guess_from_moments(groups, trials: int = 80, subset_fraction: float = 0.25, seed: int = 0):
     """Host-only part of the initial guess (no device needed)."""
     lib = cabi.load_library()

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace sba {
@@ -73,6 +74,119 @@ inline void jacobi_eigen(int n, const double* A_in, double* w, double* V) {
     for (int i = 0; i < n; ++i) Vs[i * n + k] = V[i * n + order[k]];
   }
   std::memcpy(V, Vs, sizeof(double) * n * n);
+}
+
+// Eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite n x n matrix (n <= 9) -- all a trial
+// needs from A^T A -- at a fraction of a full Jacobi decomposition (~4 k flops instead of ~50 k):
+//   1. Cholesky of A + delta I (delta = 1e-13 trace) and 10 inverse iterations from a fixed start vector,
+//   2. Rayleigh-quotient iteration (LU with partial pivoting of A - rho I) until |A x - rho x| <= 1e-15 trace,
+//   3. verification: A - (rho - 1e-12 trace) I must be positive definite (its Cholesky succeeds), i.e. no
+//      eigenvalue lies below rho -- otherwise the iteration settled on another eigenpair.
+// Returns false whenever any step is not conclusive; the caller then runs jacobi_eigen.  The sign is fixed by
+// making the largest-magnitude component positive.
+inline bool smallest_eigvec(int n, const double* A, double* v, double* lambda) {
+  double tr = 0.0;
+  for (int i = 0; i < n; ++i) tr += A[i * n + i];
+  if (!(tr > 0.0) || !std::isfinite(tr)) return false;
+  auto cholesky = [&](double shift, double* L) -> bool {   // A + shift I = L L^T
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = A[i * n + j] + (i == j ? shift : 0.0);
+        for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+        if (i == j) {
+          if (!(s > 0.0)) return false;
+          L[i * n + i] = std::sqrt(s);
+        } else {
+          L[i * n + j] = s / L[j * n + j];
+        }
+      }
+    return true;
+  };
+  auto normalise = [&](double* x) -> bool {
+    double nn = 0.0;
+    for (int i = 0; i < n; ++i) nn += x[i] * x[i];
+    if (!(nn > 0.0) || !std::isfinite(nn)) return false;
+    const double inv = 1.0 / std::sqrt(nn);
+    for (int i = 0; i < n; ++i) x[i] *= inv;
+    return true;
+  };
+  double L[81], x[9], y[9];
+  if (!cholesky(1e-13 * tr, L)) return false;
+  for (int i = 0; i < n; ++i) x[i] = 0.3 + 0.7 * ((0.6180339887498949 * (i + 1)) - std::floor(0.6180339887498949 * (i + 1)));
+  normalise(x);
+  for (int it = 0; it < 10; ++it) {
+    for (int i = 0; i < n; ++i) {               // L z = x
+      double t = x[i];
+      for (int k = 0; k < i; ++k) t -= L[i * n + k] * y[k];
+      y[i] = t / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {           // L^T y = z
+      double t = y[i];
+      for (int k = i + 1; k < n; ++k) t -= L[k * n + i] * y[k];
+      y[i] = t / L[i * n + i];
+    }
+    if (!normalise(y)) return false;
+    for (int i = 0; i < n; ++i) x[i] = y[i];
+  }
+  auto rayleigh = [&](const double* q, double* Aq) {
+    double rho = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double t = 0.0;
+      for (int k = 0; k < n; ++k) t += A[i * n + k] * q[k];
+      Aq[i] = t;
+      rho += q[i] * t;
+    }
+    return rho;
+  };
+  double Ax[9];
+  double rho = rayleigh(x, Ax);
+  bool converged = false;
+  for (int it = 0; it < 8; ++it) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += (Ax[i] - rho * x[i]) * (Ax[i] - rho * x[i]);
+    if (std::sqrt(res) <= 1e-15 * tr) { converged = true; break; }
+    double B[81], b[9];
+    for (int i = 0; i < n; ++i) {
+      b[i] = x[i];
+      for (int k = 0; k < n; ++k) B[i * n + k] = A[i * n + k] - (i == k ? rho : 0.0);
+    }
+    for (int c = 0; c < n; ++c) {                // LU with partial pivoting, a vanishing pivot is nudged
+      int piv = c;
+      for (int r = c + 1; r < n; ++r)
+        if (std::fabs(B[r * n + c]) > std::fabs(B[piv * n + c])) piv = r;
+      if (piv != c) {
+        for (int k = 0; k < n; ++k) std::swap(B[c * n + k], B[piv * n + k]);
+        std::swap(b[c], b[piv]);
+      }
+      if (std::fabs(B[c * n + c]) < 1e-300 + 1e-18 * tr) B[c * n + c] = 1e-18 * tr + 1e-300;
+      for (int r = c + 1; r < n; ++r) {
+        const double f = B[r * n + c] / B[c * n + c];
+        for (int k = c; k < n; ++k) B[r * n + k] -= f * B[c * n + k];
+        b[r] -= f * b[c];
+      }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double t = b[i];
+      for (int k = i + 1; k < n; ++k) t -= B[i * n + k] * y[k];
+      y[i] = t / B[i * n + i];
+    }
+    if (!normalise(y)) return false;
+    for (int i = 0; i < n; ++i) x[i] = y[i];
+    rho = rayleigh(x, Ax);
+  }
+  if (!converged) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += (Ax[i] - rho * x[i]) * (Ax[i] - rho * x[i]);
+    if (!(std::sqrt(res) <= 1e-13 * tr)) return false;
+  }
+  if (!cholesky(-(rho - 1e-12 * tr), L)) return false;   // an eigenvalue below rho: not the smallest pair
+  int big = 0;
+  for (int i = 1; i < n; ++i)
+    if (std::fabs(x[i]) > std::fabs(x[big])) big = i;
+  const double sgn = x[big] < 0.0 ? -1.0 : 1.0;
+  for (int i = 0; i < n; ++i) v[i] = sgn * x[i];
+  *lambda = rho;
+  return true;
 }
 
 inline double det3(const double* M) {
@@ -192,9 +306,11 @@ inline void trial_from_moments(const double* mom45, float e1[3], float e2[3], fl
   int k = 0;
   for (int a = 0; a < 9; ++a)
     for (int b = a; b < 9; ++b) { S[9 * a + b] = S[9 * b + a] = mom45[k]; ++k; }
-  jacobi_eigen(9, S, w, V);
-  double E[9];
-  for (int i = 0; i < 9; ++i) E[i] = V[9 * i + 0];      // eigenvector of the smallest eigenvalue (.cpp:72-74)
+  double E[9], lam_min;                                  // eigenvector of the smallest eigenvalue (.cpp:72-74)
+  if (!smallest_eigvec(9, S, E, &lam_min)) {
+    jacobi_eigen(9, S, w, V);
+    for (int i = 0; i < 9; ++i) E[i] = V[9 * i + 0];
+  }
   // rank-2 correction: zero the smallest singular value (.cpp:75-80)
   double U[9], sv[3], Vt[9], T[9], Ec[9];
   svd3(E, U, sv, Vt);
@@ -218,14 +334,17 @@ inline int consensus_pick(const std::vector<Candidate>& c) {
   if (r == 0) return -1;
   int best = 0;
   double best_d = 0;
+  std::vector<double> d(r);
+  const int lo = static_cast<int>(r * 0.2), hi = static_cast<int>(r * 0.8);
   for (int i = 0; i < r; ++i) {
-    std::vector<double> d(r);
     for (int j = 0; j < r; ++j) {
       const float dx = c[i].euler[0] - c[j].euler[0], dy = c[i].euler[1] - c[j].euler[1], dz = c[i].euler[2] - c[j].euler[2];
       d[j] = std::sqrt(static_cast<double>(dx * dx + dy * dy + dz * dz));
     }
-    std::sort(d.begin(), d.end());
-    const int lo = static_cast<int>(r * 0.2), hi = static_cast<int>(r * 0.8);
+    // only the 20-80 % middle is summed: select it, then sort just that part (same summation order as a full sort)
+    if (lo < r) std::nth_element(d.begin(), d.begin() + lo, d.end());
+    if (hi < r) std::nth_element(d.begin() + lo, d.begin() + hi, d.end());
+    std::sort(d.begin() + lo, d.begin() + hi);
     double acc = 0.0;
     for (int j = lo; j < hi; ++j) acc += d[j];
     const double avg = acc / (static_cast<double>(hi - lo) * 1.0);    // 0/0 = NaN for r < 2, as in the reference
@@ -243,24 +362,46 @@ struct GuessResult {
 };
 
 // groups: [64][45] moments, counts not needed.  trials / fraction / seed: 80, 0.25 in the reference.
-inline GuessResult initial_guess_from_groups(const double* groups, int trials, double fraction, uint64_t seed) {
+// Trials are independent (the subset of trial k depends on (seed, k) only), so they run on `threads` host threads --
+// what the reference's set_omp(num_proc) does for its loops -- and are collected in trial order: the result does not
+// depend on the thread count.
+inline GuessResult initial_guess_from_groups(const double* groups, int trials, double fraction, uint64_t seed,
+                                             int threads = 1) {
   GuessResult res;
   const int take = std::max(1, std::min(kGroups, static_cast<int>(kGroups * fraction)));
+  struct TrialOut { Candidate c1, c2; bool v1, v2; };
+  std::vector<TrialOut> out(static_cast<size_t>(std::max(trials, 0)));
+  auto run = [&](int first, int last) {
+    for (int trial = first; trial < last; ++trial) {
+      int sel[kGroups];
+      trial_groups(seed, trial, take, sel);
+      std::sort(sel, sel + take);                     // fixed summation order
+      double mom[kMom] = {0};
+      for (int s = 0; s < take; ++s)
+        for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
+      TrialOut& o = out[trial];
+      o.c1 = Candidate{}; o.c2 = Candidate{}; o.v1 = o.v2 = false;
+      float tv[3];
+      trial_from_moments(mom, o.c1.euler, o.c2.euler, tv, &o.v1, &o.v2, nullptr);
+      for (int i = 0; i < 3; ++i) o.c1.tran[i] = o.c2.tran[i] = tv[i];
+      o.c1.trial = o.c2.trial = trial; o.c1.which = 1; o.c2.which = 2;
+    }
+  };
+  // A trial is ~6 us and starting a thread costs tens of us: threads only pay with hundreds of trials each, so the
+  // reference's 80 trials always run serially.
+  const int nt = std::max(1, std::min(threads, trials / 256));
+  if (nt <= 1) {
+    run(0, trials);
+  } else {
+    std::vector<std::thread> pool;
+    const int per = (trials + nt - 1) / nt;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(run, std::min(trials, t * per), std::min(trials, (t + 1) * per));
+    run(0, std::min(trials, per));
+    for (auto& th : pool) th.join();
+  }
   for (int trial = 0; trial < trials; ++trial) {
-    int sel[kGroups];
-    trial_groups(seed, trial, take, sel);
-    std::sort(sel, sel + take);                     // fixed summation order
-    double mom[kMom] = {0};
-    for (int s = 0; s < take; ++s)
-      for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
-    Candidate c1{}, c2{};
-    bool v1 = false, v2 = false;
-    float tv[3];
-    trial_from_moments(mom, c1.euler, c2.euler, tv, &v1, &v2, nullptr);
-    for (int i = 0; i < 3; ++i) c1.tran[i] = c2.tran[i] = tv[i];
-    c1.trial = c2.trial = trial; c1.which = 1; c2.which = 2;
-    if (v1) res.candidates.push_back(c1);            // .cpp:148-157: T_vec is pushed with either rotation
-    if (v2) res.candidates.push_back(c2);
+    if (out[trial].v1) res.candidates.push_back(out[trial].c1);   // .cpp:148-157: T_vec is pushed with either rotation
+    if (out[trial].v2) res.candidates.push_back(out[trial].c2);
   }
   res.num_candidates = static_cast<int>(res.candidates.size());
   res.picked = consensus_pick(res.candidates);

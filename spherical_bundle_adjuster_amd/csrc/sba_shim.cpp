@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -23,6 +25,14 @@
 #include "sba_rotation.hpp"
 
 namespace {
+
+// Host threads for the host-side loops that have any (the 80 trials of the initial guess): sba_set_host_threads,
+// initialised from SBA_HOST_THREADS; 1 = serial.  Results do not depend on it.
+std::atomic<int> g_host_threads{[] {
+  const char* env = std::getenv("SBA_HOST_THREADS");
+  const int v = env ? std::atoi(env) : 1;
+  return v >= 1 && v <= 256 ? v : 1;
+}()};
 
 thread_local std::string g_last_error;
 
@@ -411,6 +421,13 @@ int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
 extern "C" {
 
 int sba_abi_version(void) { return SBA_ABI_VERSION; }
+
+int sba_set_host_threads(int n) {
+  if (n < 0) return fail(SBA_ERR_INVALID_ARG, "thread count must be >= 0 (0 = one per hardware thread, at most 16)");
+  if (n == 0) n = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+  g_host_threads.store(n);
+  return SBA_OK;
+}
 const char* sba_last_error(void) { return g_last_error.c_str(); }
 
 int sba_device_count(int* count) {
@@ -1099,7 +1116,8 @@ int sba_initial_guess_from_moments(const double* groups, int trials, double subs
   if (!groups || !rot_euler || !tran) return fail(SBA_ERR_INVALID_ARG, "null argument");
   if (trials < 1 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
     return fail(SBA_ERR_INVALID_ARG, "bad trials / subset_fraction");
-  const sba::epi::GuessResult r = sba::epi::initial_guess_from_groups(groups, trials, subset_fraction, seed);
+  const sba::epi::GuessResult r = sba::epi::initial_guess_from_groups(groups, trials, subset_fraction, seed,
+                                                                       g_host_threads.load());
   if (num_candidates) *num_candidates = r.num_candidates;
   if (r.picked < 0) return fail(SBA_ERR_NUMERIC, "no valid rotation candidate (all Euler angles >= 1.57)");
   for (int i = 0; i < 3; ++i) { rot_euler[i] = r.euler[i]; tran[i] = r.tran[i]; }

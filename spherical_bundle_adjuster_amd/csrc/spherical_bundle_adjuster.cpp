@@ -18,8 +18,10 @@ spherical_bundle_adjuster::~spherical_bundle_adjuster() {
 
 void spherical_bundle_adjuster::set_omp(int n) {
   // The reference sets the process-global OpenMP thread count (.cpp:835-841) for its CPU loops and for
-  // Ceres.  The GPU path has no host loops over matches; the value is kept for interface parity.
+  // Ceres.  The GPU path has no host loops over matches; the one host loop worth threads is the 80 trials of the
+  // initial guess, which run on that many host threads (the result does not depend on the count).
   num_proc = n;
+  if (n >= 1) sba_set_host_threads(n);
   std::cout << "Number of process: " << num_proc << std::endl;
 }
 

@@ -3,6 +3,7 @@
 using namespace sba::epi;
 extern "C" {
 void harness_jacobi(int n, const double* A, double* w, double* V) { jacobi_eigen(n, A, w, V); }
+int harness_smallest_eigvec(int n, const double* A, double* v, double* lambda) { return smallest_eigvec(n, A, v, lambda) ? 1 : 0; }
 void harness_svd3(const double* E, double* U, double* w, double* Vt) { svd3(E, U, w, Vt); }
 void harness_decompose(const double* E, double* R1, double* R2, double* t) { decompose_essential(E, R1, R2, t); }
 void harness_euler(const double* R, float* out) { rot_to_euler(R, out); }

@@ -65,6 +65,39 @@ def test_jacobi_and_svd3_vs_numpy():
         assert np.abs(U.T @ U - np.eye(3)).max() < 1e-13 and np.abs(Vt @ Vt.T - np.eye(3)).max() < 1e-13 and w[0] >= w[1] >= w[2]
 
 
+def test_smallest_eigvec_fast_path_vs_numpy():
+    """The verified shortcut for the smallest eigenpair (what a trial needs from A^T A): whenever it reports success it
+    must agree with LAPACK; inconclusive cases (clustered smallest eigenvalues, non-PSD input) must say so, because the
+    caller then falls back to the full Jacobi decomposition."""
+    rng = np.random.default_rng(5)
+    h = harness()
+    h.harness_smallest_eigvec.restype = C.c_int
+    ok = 0
+    for trial in range(300):
+        n = 9 if trial % 3 else 3
+        rows = n - 1 if trial % 7 == 0 else n + 6                  # rank-deficient (exact null vector) and full rank
+        M = rng.standard_normal((rows, n)) * 10.0 ** rng.uniform(-3, 3)
+        S = M.T @ M
+        v, lam = np.zeros(n), np.zeros(1)
+        if h.harness_smallest_eigvec(C.c_int(n), _p(S), _p(v), _p(lam)):
+            ok += 1
+            wn, Vn = np.linalg.eigh(S)
+            assert abs(lam[0] - wn[0]) <= 1e-12 * wn[-1]
+            assert abs(np.linalg.norm(v) - 1) < 1e-14 and v[np.argmax(np.abs(v))] > 0
+            gap = (wn[1] - wn[0]) / wn[-1]
+            assert np.abs(v - Vn[:, 0] * np.sign(Vn[:, 0] @ v)).max() <= 1e-13 / max(gap, 1e-13)
+            assert np.abs(S @ v - lam[0] * v).max() <= 1e-13 * wn[-1]
+    assert ok >= 280                                               # the fast path is the normal case
+    # exactly repeated smallest eigenvalue: any vector of the eigenspace is acceptable if success is reported
+    S = np.diag([1.0, 1.0, 5.0])
+    v, lam = np.zeros(3), np.zeros(1)
+    if h.harness_smallest_eigvec(C.c_int(3), _p(S), _p(v), _p(lam)):
+        assert abs(lam[0] - 1.0) < 1e-12 and abs(v[2]) < 1e-6
+    # not positive semi-definite / all-zero: must decline
+    for S in (np.diag([1.0, -2.0, 3.0]), np.zeros((3, 3))):
+        assert h.harness_smallest_eigvec(C.c_int(3), _p(np.ascontiguousarray(S)), _p(v), _p(lam)) == 0
+
+
 def test_decompose_essential_recovers_motion():
     rng = np.random.default_rng(1)
     for _ in range(10):
@@ -127,5 +160,19 @@ def test_initial_guess_known_answer_and_determinism():
     G, _, _ = group_moments(c.x1, c.x2)
     e, t, _ = api.initial_guess_from_moments(G, 80, 0.25, seed=2)
     assert np.abs(e - euler_of(synthetic.rodrigues(c.rot_true).T)).max() < 0.1
+    # host threads (the reference's set_omp): the trials are collected in trial order, so the count never matters
+    try:
+        for threads in (2, 5, 8, 0):
+            api.set_host_threads(threads)
+            et, tt_, nt = api.initial_guess_from_moments(G, 80, 0.25, seed=2)
+            assert np.array_equal(et, e) and np.array_equal(tt_, t), threads
+            e7, t7, n7 = api.initial_guess_from_moments(G, 1100, 0.25, seed=2)   # enough trials for several threads
+            api.set_host_threads(1)
+            e7s, t7s, n7s = api.initial_guess_from_moments(G, 1100, 0.25, seed=2)
+            assert np.array_equal(e7, e7s) and np.array_equal(t7, t7s) and n7 == n7s
+        with pytest.raises(api.SbaError):
+            api.set_host_threads(-1)
+    finally:
+        api.set_host_threads(1)
     with pytest.raises(api.SbaError):
         api.initial_guess_from_moments(G, 0, 0.25)
