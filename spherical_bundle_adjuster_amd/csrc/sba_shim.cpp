@@ -143,6 +143,8 @@ struct sba_problem {
   int kind = SBA_KERNEL_FACTORED;
   int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
   int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
+  double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
+  size_t epi_scratch_elems = 0;
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
   int last_mode = 0;
 
@@ -512,6 +514,7 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->partials) (void)hipFree(p->partials);
   if (p->pack_dev) (void)hipFree(p->pack_dev);
   if (p->ticket) (void)hipFree(p->ticket);
+  if (p->epi_scratch) (void)hipFree(p->epi_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1089,10 +1092,15 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
   const size_t nquad = (p->n + 3) / 4;
   const int grid = static_cast<int>(std::min<size_t>((nquad + 63) / 64, static_cast<size_t>(p->num_cus) * 4));
   const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
-  sba::DeviceBuffer partials_buf, groups_buf;
-  SBA_HIP_TRY(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * gsz * sizeof(double)));
-  SBA_HIP_TRY(groups_buf.alloc(gsz * sizeof(double)));
-  double *partials = partials_buf.as<double>(), *groups_dev = groups_buf.as<double>();
+  // scratch (block partials + the groups) lives in the handle: allocating 23 MB per call cost more than the pass
+  const size_t need = (static_cast<size_t>(std::max(grid, 1)) + 1) * gsz;
+  if (p->epi_scratch_elems < need) {
+    if (p->epi_scratch) SBA_HIP_TRY(hipFree(p->epi_scratch));
+    p->epi_scratch = nullptr; p->epi_scratch_elems = 0;
+    SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->epi_scratch), need * sizeof(double)));
+    p->epi_scratch_elems = need;
+  }
+  double *groups_dev = p->epi_scratch, *partials = p->epi_scratch + gsz;
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
   pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
