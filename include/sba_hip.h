@@ -315,7 +315,8 @@ int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction
 /* The reference handles one image pair per process run (main/main.cpp:6-34); a batch holds `num_pairs`
  * independent problems on one GPU: pair g owns correspondences [offsets[g], offsets[g+1]) of the
  * concatenated arrays (same layouts as sba_problem_upload; offsets has num_pairs+1 entries, ragged and empty
- * pairs allowed).  ONE kernel launch evaluates every pair at its own (rot, tran); sba_batch_solve runs one LM per
+ * pairs allowed).  ONE sweep launch evaluates every pair at its own (rot, tran) -- the per-pair sweep state and the
+ * mapping of the reduced moments to normal equations are computed on the device as well; sba_batch_solve runs one LM per
  * pair in lock-step (same schedule as sba_problem_solve).  Pairs are independent, so across GPUs they are
  * simply split between processes -- no collective.                                                        */
 typedef struct sba_batch sba_batch;

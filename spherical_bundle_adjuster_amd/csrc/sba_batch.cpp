@@ -30,8 +30,10 @@ struct sba_batch {
   void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* dplane[2] = {nullptr, nullptr};
   sba::PairDesc* desc_dev = nullptr;
-  sba::SweepParams* params_dev = nullptr;
-  sba::SweepParams* params_host = nullptr;   // pinned
+  sba::SweepParams* params_dev = nullptr;    // built on the device by batch_prepare_kernel
+  sba::BatchState* state_host = nullptr;     // pinned + mapped: what the host hands over per pair and step (80 B)
+  sba::BatchState* state_host_dev = nullptr; // device-visible address of state_host
+  double* frames_dev = nullptr;              // [pair][18]: (B, J) of the pair's rotation, for the moment conversion
   double* partials = nullptr;
   int bpp = 1;                                // blocks per pair
   double* packs_dev = nullptr;
@@ -48,11 +50,13 @@ int free_batch_data(sba_batch* b) {
   for (auto& d : b->dplane) { if (d) SBA_TRY_HIP(hipFree(d)); d = nullptr; }
   if (b->desc_dev) SBA_TRY_HIP(hipFree(b->desc_dev));
   if (b->params_dev) SBA_TRY_HIP(hipFree(b->params_dev));
-  if (b->params_host) SBA_TRY_HIP(hipHostFree(b->params_host));
+  if (b->state_host) SBA_TRY_HIP(hipHostFree(b->state_host));
+  if (b->frames_dev) SBA_TRY_HIP(hipFree(b->frames_dev));
   if (b->partials) SBA_TRY_HIP(hipFree(b->partials));
   if (b->packs_dev) SBA_TRY_HIP(hipFree(b->packs_dev));
   if (b->packs_host) SBA_TRY_HIP(hipHostFree(b->packs_host));
-  b->desc_dev = nullptr; b->params_dev = nullptr; b->params_host = nullptr; b->partials = nullptr;
+  b->desc_dev = nullptr; b->params_dev = nullptr; b->state_host = nullptr; b->state_host_dev = nullptr;
+  b->frames_dev = nullptr; b->partials = nullptr;
   b->packs_dev = nullptr; b->packs_host = nullptr; b->packs_host_dev = nullptr;
   b->uploaded = false; b->num_pairs = 0; b->n.clear(); b->first_vec.clear();
   return SBA_OK;
@@ -70,37 +74,41 @@ int check_batch_args(const sba_batch* b, int mode, int depth_mode, const double*
   return SBA_OK;
 }
 
-// One batched launch: pair g is evaluated at (rot[g], tran[g]) unless active[g] == 0.  packs_host then holds
-// the raw device packs (moment layout for the factored kernel).
+// One batched step: pair g is evaluated at (rot[g], tran[g]) unless active[g] == 0.  The host writes 80 bytes per pair
+// into mapped pinned memory; batch_prepare_kernel builds every pair's sweep state from it ON THE DEVICE, the sweep runs,
+// and the finalize kernel folds the rows, maps the factored kernel's moments to the SBA_PACK_* layout (also on the
+// device) and publishes all packs into mapped host memory followed by a sequence word the host polls.  packs_host then
+// holds the final packs.
 int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran, const double* d1,
                  const double* d2, double huber_delta, const unsigned char* active, double* prepare_ms = nullptr) {
   const int B = b->num_pairs;
   const auto t_prep = std::chrono::steady_clock::now();
   for (int g = 0; g < B; ++g) {
-    const bool on = !active || active[g];
-    sba::make_sweep_params(on ? b->n[g] : 0, depth_mode, rot + 3 * g, tran + 3 * g, d1 ? d1[g] : 1.0,
-                           d2 ? d2[g] : 1.0, huber_delta, &b->params_host[g]);
+    sba::BatchState& st = b->state_host[g];
+    for (int a = 0; a < 3; ++a) { st.rot[a] = rot[3 * g + a]; st.tran[a] = tran[3 * g + a]; }
+    st.d1 = d1 ? d1[g] : 1.0;
+    st.d2 = d2 ? d2[g] : 1.0;
+    st.n = (!active || active[g]) ? b->n[g] : 0;
+    st.pad_ = 0;
   }
   if (prepare_ms)
     *prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep).count();
-  SBA_TRY_HIP(hipMemcpyAsync(b->params_dev, b->params_host, sizeof(sba::SweepParams) * B, hipMemcpyHostToDevice,
-                             b->stream));
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
   pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
   if (!b->publish) {
-    SBA_TRY_HIP(sba::launch_batch_sweep(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
-                                        b->desc_dev, B, b->bpp, b->partials, b->packs_dev, nullptr, 0, b->stream));
+    SBA_TRY_HIP(sba::launch_batch_step(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
+                                       b->params_dev, b->frames_dev, b->desc_dev, B, b->bpp, b->partials, b->packs_dev,
+                                       nullptr, 0, b->stream));
     SBA_TRY_HIP(hipMemcpyAsync(b->packs_host, b->packs_dev, sizeof(double) * 24 * B, hipMemcpyDeviceToHost, b->stream));
     SBA_TRY_HIP(hipStreamSynchronize(b->stream));
     return SBA_OK;
   }
-  // The finalize kernel stores the packs into mapped host memory, fences at system scope, then stores the sequence
-  // number: poll it.  A stream query every so often turns a device fault into an error instead of an endless spin.
+  // A stream query every so often turns a device fault into an error instead of an endless spin.
   const unsigned long long seq = ++b->seq;
-  SBA_TRY_HIP(sba::launch_batch_sweep(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
-                                      b->desc_dev, B, b->bpp, b->partials, b->packs_dev, b->packs_host_dev, seq,
-                                      b->stream));
+  SBA_TRY_HIP(sba::launch_batch_step(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
+                                     b->params_dev, b->frames_dev, b->desc_dev, B, b->bpp, b->partials, b->packs_dev,
+                                     b->packs_host_dev, seq, b->stream));
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B);
   for (unsigned long spins = 0; *flag != seq; ++spins) {
     if ((spins & 0xfff) == 0xfff) {
@@ -116,14 +124,9 @@ int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, cons
   return SBA_OK;
 }
 
-void convert_pack(const sba_batch* b, int mode, const double rot[3], const double* raw, double* pack) {
-  if (b->kind == SBA_KERNEL_FACTORED && mode != SBA_MODE_TRAN) {
-    double Bm[9], J[9];
-    sba::factored_frame(rot, Bm, J);
-    sba::moments_to_normal_pack(true, mode == SBA_MODE_RT, Bm, J, raw, pack);
-  } else {
-    std::memcpy(pack, raw, sizeof(double) * 24);
-  }
+// The packs arrive in the SBA_PACK_* layout (the finalize kernel converts the factored kernel's moments on the device).
+void convert_pack(const sba_batch*, int, const double*, const double* raw, double* pack) {
+  std::memcpy(pack, raw, sizeof(double) * 24);
 }
 
 }  // namespace
@@ -229,7 +232,11 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->desc_dev), sizeof(sba::PairDesc) * num_pairs));
   SBA_TRY_HIP(hipMemcpy(b->desc_dev, desc.data(), sizeof(sba::PairDesc) * num_pairs, hipMemcpyHostToDevice));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->params_dev), sizeof(sba::SweepParams) * num_pairs));
-  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->params_host), sizeof(sba::SweepParams) * num_pairs, hipHostMallocDefault));
+  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->state_host), sizeof(sba::BatchState) * num_pairs,
+                            hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(b->state_host, 0, sizeof(sba::BatchState) * num_pairs);
+  SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->state_host_dev), b->state_host, 0));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->frames_dev), sizeof(double) * 18 * num_pairs));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->partials), sizeof(double) * sba::kRow * num_pairs * b->bpp));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->packs_dev), sizeof(double) * 24 * num_pairs));
   SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->packs_host), sizeof(double) * (24 * num_pairs + 8),

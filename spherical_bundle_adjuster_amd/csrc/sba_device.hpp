@@ -5,6 +5,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "sba_rotation.hpp"
+
 namespace sba {
 
 // Wave-uniform state of one sweep, passed BY VALUE as a kernel argument (kernarg segment ->
@@ -22,6 +24,21 @@ struct SweepParams {
   unsigned long long n;  // correspondences in this shard
 };
 static_assert(sizeof(SweepParams) == 43 * 8, "SweepParams layout");
+
+// Per-sweep state from (rot, tran, depths, delta).  depth_mode: 0 = uniform (d1 folded into Rn / Gn), 1 = per match.
+SBA_HD inline void fill_sweep_params(unsigned long long n, int depth_mode, const double rot[3], const double tran[3],
+                                     double d1, double d2, double huber_delta, SweepParams* prm) {
+  double R[9], G[27];
+  rotation_and_derivatives(rot, R, G);
+  const double scale = depth_mode == 0 ? -d1 : -1.0;
+  for (int i = 0; i < 9; ++i) prm->Rn[i] = scale * R[i];
+  for (int i = 0; i < 27; ++i) prm->Gn[i] = scale * G[i];
+  for (int i = 0; i < 3; ++i) prm->t[i] = tran[i];
+  prm->d2 = d2;
+  prm->delta = huber_delta > 0.0 ? huber_delta : 0.0;
+  prm->delta2 = prm->delta * prm->delta;
+  prm->n = n;
+}
 
 // Device-resident correspondences as planes (structure of arrays): every lane of a wave reads
 // 16 consecutive bytes of one plane, so each wave load instruction covers 1 KiB contiguous.
@@ -87,11 +104,26 @@ struct PairDesc {
   unsigned long long first_vec;
   unsigned long long n;
 };
+// What the host hands over per pair and step (mapped pinned host memory, 80 B per pair): the point to evaluate at and
+// the number of matches that take part (0 = pair already converged).
+struct BatchState {
+  double rot[3], tran[3];
+  double d1, d2;
+  unsigned long long n;
+  unsigned long long pad_;
+};
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
                               double* partials, double* packs, double* packs_host, unsigned long long seq,
                               hipStream_t stream);
+// Same, with the per-pair preparation and conversion on the device: batch_prepare_kernel builds every pair's
+// SweepParams (and, for the factored kernel, the frame (B, J) of its rotation) from `state`; batch_finalize_kernel folds
+// the rows and maps the factored kernel's moments to the SBA_PACK_* layout before publishing.
+hipError_t launch_batch_step(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
+                             const BatchState* state, SweepParams* params, double* frames, const PairDesc* desc,
+                             int num_pairs, int bpp, double* partials, double* packs, double* packs_host,
+                             unsigned long long seq, hipStream_t stream);
 
 // AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.
 hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void* px, void* py,

@@ -527,6 +527,71 @@ __global__ __launch_bounds__(1024) void batch_finalize_kernel(const double* __re
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- batched step with the per-pair host work moved to the device ----------------------------------------------
+// One thread per pair: SweepParams (rotation, its derivatives, the Huber constants) from the pair's (rot, tran, depths)
+// in `state` (mapped host memory: 80 B per pair instead of the 344-byte SweepParams crossing PCIe), and for the factored
+// kernel the frame (B, J) that batch_convert_finalize_kernel applies to the pair's moments.
+__global__ __launch_bounds__(64) void batch_prepare_kernel(const BatchState* __restrict__ state, int num_pairs,
+                                                           int depth_mode, double huber_delta, int with_frames,
+                                                           SweepParams* __restrict__ params,
+                                                           double* __restrict__ frames) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= num_pairs) return;
+  const BatchState st = state[g];
+  SweepParams prm;
+  fill_sweep_params(st.n, depth_mode, st.rot, st.tran, st.d1, st.d2, huber_delta, &prm);
+  params[g] = prm;
+  if (with_frames) {
+    double B[9], J[9];
+    factored_frame(st.rot, B, J);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { frames[18 * g + i] = B[i]; frames[18 * g + 9 + i] = J[i]; }
+  }
+}
+
+// Fold (as batch_finalize_kernel), then one thread per pair maps the moment pack to the SBA_PACK_* layout with the
+// pair's own frame, and everything is published to the host.  convert: 1 = rot free, 2 = rot + tran free.
+__global__ __launch_bounds__(1024) void batch_convert_finalize_kernel(const double* __restrict__ partials, int bpp,
+                                                                      int num_pairs, const double* __restrict__ frames,
+                                                                      int convert, double* __restrict__ packs,
+                                                                      double* __restrict__ packs_host,
+                                                                      unsigned long long seq) {
+  const int items = num_pairs * 24;
+  for (int it = threadIdx.x; it < items; it += 1024) {
+    const int pair = it / 24, slot = it - pair * 24;
+    const double* rows = partials + static_cast<size_t>(pair) * bpp * kRow + slot;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < bpp; b += 4) {
+      s0 += rows[static_cast<size_t>(b) * kRow];
+      s1 += rows[static_cast<size_t>(b + 1) * kRow];
+      s2 += rows[static_cast<size_t>(b + 2) * kRow];
+      s3 += rows[static_cast<size_t>(b + 3) * kRow];
+    }
+    for (; b < bpp; ++b) s0 += rows[static_cast<size_t>(b) * kRow];
+    packs[it] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();                                         // the raw packs of this block are visible to all its threads
+  for (int pair = threadIdx.x; pair < num_pairs; pair += 1024) {
+    double raw[24], out[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) raw[k] = packs[pair * 24 + k];
+    moments_to_normal_pack(true, convert == 2, frames + 18 * pair, frames + 18 * pair + 9, raw, out);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      packs[pair * 24 + k] = out[k];
+      if (packs_host) packs_host[pair * 24 + k] = out[k];
+    }
+  }
+  if (!packs_host) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + items), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- direct peer exchange over xGMI: the all-reduce of the 24-double pack without a collective library ----------
 // Every rank owns an "inbox" in fine-grained device memory, mapped into all peers through HIP IPC:
 //     inbox[parity][source rank][32]   (24 doubles of payload, word 31 = sequence number; 256 B per slot)
@@ -869,6 +934,31 @@ hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool los
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
                      packs_host, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_step(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
+                             const BatchState* state, SweepParams* params, double* frames, const PairDesc* desc,
+                             int num_pairs, int bpp, double* partials, double* packs, double* packs_host,
+                             unsigned long long seq, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchFn fn = bpick(mode, depth, store, kind, huber_delta > 0.0);
+  if (!fn) return hipErrorInvalidValue;
+  const int convert = (kind == KIND_FACTORED && mode != MODE_TRAN) ? (mode == MODE_RT ? 2 : 1) : 0;
+  hipLaunchKernelGGL(batch_prepare_kernel, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, state, num_pairs, depth,
+                     huber_delta, convert != 0 ? 1 : 0, params, frames);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs) * bpp), dim3(kBlock), 0, stream, pl, params, desc, bpp,
+                     partials);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (convert != 0)
+    hipLaunchKernelGGL(batch_convert_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, frames,
+                       convert, packs, packs_host, seq);
+  else
+    hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
+                       packs_host, seq);
   return hipGetLastError();
 }
 

@@ -23,6 +23,14 @@
 #include <cfloat>
 #include <cmath>
 
+// The same source serves the host (single-problem path, g++-built test harness) and the device (the batched path
+// prepares every pair's state and converts every pair's moments in its own kernels).
+#if defined(__HIPCC__)
+#define SBA_HD __host__ __device__
+#else
+#define SBA_HD
+#endif
+
 namespace sba {
 
 // a = sin(th)/th, b = (1-cos th)/th^2, c = (th - sin th)/th^3, ap = (da/dth)/th, bp = (db/dth)/th.
@@ -30,7 +38,7 @@ namespace sba {
 // bp loses ~2 eps / x^2), closed forms above, where they are accurate to a few eps.
 //   a = sum (-x)^k/(2k+1)!   b = sum (-x)^k/(2k+2)!   c = sum (-x)^k/(2k+3)!
 //   bp = (a - 2b)/x = sum_{k>=1} (-1)^k 2k x^(k-1)/(2k+2)!
-inline void so3_coefficients(double x /* th^2 */, double* a, double* b, double* c, double* ap, double* bp) {
+SBA_HD inline void so3_coefficients(double x /* th^2 */, double* a, double* b, double* c, double* ap, double* bp) {
   if (x < 0.25) {
     double sa = 0, sb = 0, sc = 0, sbp = 0;
     double pw = 1.0;      // (-x)^k
@@ -56,9 +64,9 @@ inline void so3_coefficients(double x /* th^2 */, double* a, double* b, double* 
 }
 
 // R: row-major 3x3.  G: G[9*j + 3*r + c] = d R[r][c] / d w_j.
-inline void rotation_and_derivatives(const double w[3], double R[9], double G[27]) {
+SBA_HD inline void rotation_and_derivatives(const double w[3], double R[9], double G[27]) {
   const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  static const double E[3][9] = {{0, 0, 0, 0, 0, -1, 0, 1, 0},     // [e_j]x, row-major
+  const double E[3][9] = {{0, 0, 0, 0, 0, -1, 0, 1, 0},     // [e_j]x, row-major
                                  {0, 0, 1, 0, 0, 0, -1, 0, 0},
                                  {0, -1, 0, 1, 0, 0, 0, 0, 0}};
   const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
@@ -88,7 +96,7 @@ inline void rotation_and_derivatives(const double w[3], double R[9], double G[27
 // For the factored kernel: A = -[B v]x J with v = -d1 R x1.
 //   th2 >  eps: B = I,              J = J_l(w) = I + b [w]x + c ([w]x)^2
 //   th2 <= eps: B = (I + [w]x)^-1,  J = I
-inline void factored_frame(const double w[3], double B[9], double J[9]) {
+SBA_HD inline void factored_frame(const double w[3], double B[9], double J[9]) {
   const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
   const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
   for (int i = 0; i < 9; ++i) B[i] = J[i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -109,7 +117,7 @@ inline void factored_frame(const double w[3], double B[9], double J[9]) {
 // Device moment pack (factored kernel) -> normal-equation pack (SBA_PACK_* layout of sba_hip.h).
 //   moment: [0..5] M upper 00 01 02 11 12 22, [6..14] C[k][l] = sum w v_k e_l, [15] sum w,
 //           [16..18] m = sum w v, [19..21] sum w e, [22] cost, [23] n_outlier
-inline void moments_to_normal_pack(bool rot_free, bool tran_free, const double B[9], const double J[9],
+SBA_HD inline void moments_to_normal_pack(bool rot_free, bool tran_free, const double B[9], const double J[9],
                                    const double* mom, double* pack) {
   for (int i = 0; i < 24; ++i) pack[i] = 0.0;
   pack[15] = mom[15];

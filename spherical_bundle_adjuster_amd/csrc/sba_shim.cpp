@@ -59,16 +59,8 @@ int set_error(int code, const char* fmt, ...) {
 }
 void make_sweep_params(size_t n, int depth_mode, const double rot[3], const double tran[3], double d1, double d2,
                        double huber_delta, SweepParams* prm) {
-  double R[9], G[27];
-  rotation_and_derivatives(rot, R, G);
-  const double scale = depth_mode == SBA_DEPTH_UNIFORM ? -d1 : -1.0;
-  for (int i = 0; i < 9; ++i) prm->Rn[i] = scale * R[i];
-  for (int i = 0; i < 27; ++i) prm->Gn[i] = scale * G[i];
-  for (int i = 0; i < 3; ++i) prm->t[i] = tran[i];
-  prm->d2 = d2;
-  prm->delta = huber_delta > 0.0 ? huber_delta : 0.0;
-  prm->delta2 = prm->delta * prm->delta;
-  prm->n = n;
+  static_assert(SBA_DEPTH_UNIFORM == 0, "fill_sweep_params takes 0 for uniform depths");
+  fill_sweep_params(n, depth_mode, rot, tran, d1, d2, huber_delta, prm);   // same source as the batched path's device side
 }
 }  // namespace sba
 
