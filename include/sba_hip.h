@@ -287,7 +287,8 @@ int sba_problem_set_shard(sba_problem* p, int rank, int nranks);
  * correspondences in either kernel's layout, so summing it across shards is exact).            */
 int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr);
 
-/* Host threads for the host-side loops that have any (today: the trials of the initial guess) -- the counterpart of
+/* Host threads for the host-side loops that have any (the trials of the initial guess; the per-pair LM steps of
+ * sba_batch_solve, from 64 pairs per thread) -- the counterpart of
  * the reference's set_omp(num_proc) (.cpp:835-841).  0 = one per hardware thread (at most 16); default 1, or
  * SBA_HOST_THREADS.  Process-wide; results do not depend on it.  A trial costs a few microseconds, so threads are
  * only started when there are at least 256 trials per thread (the reference's 80 trials run serially).           */

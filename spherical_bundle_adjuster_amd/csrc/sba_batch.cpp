@@ -3,10 +3,13 @@
 // evaluates every pair at its own R|t, and one host LmSolver per pair advances in lock-step off that launch.
 // Pairs are independent: across GPUs they shard without any collective.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "sba_internal.hpp"
@@ -128,6 +131,52 @@ int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, cons
 void convert_pack(const sba_batch*, int, const double*, const double* raw, double* pack) {
   std::memcpy(pack, raw, sizeof(double) * 24);
 }
+
+// Host threads for the per-pair LM steps of sba_batch_solve (sba_set_host_threads, the reference's set_omp): the pool
+// lives for one solve; workers spin on a generation counter between steps (a step is ~0.2 ms, parking them would cost
+// more than it saves), each owns a fixed contiguous range of pairs, so the result does not depend on the count.
+class PairWorkers {
+ public:
+  template <typename Fn>
+  PairWorkers(int threads, int pairs, Fn fn) : pairs_(pairs) {
+    // a pair's LM step is ~0.5 us and starting a thread costs ~50 us per solve: at least 64 pairs per thread
+    // (256 pairs x 50k: 1.15 ms with 1 thread, 1.07 ms with 4, 1.38 ms when forced to 8)
+    nt_ = std::max(1, std::min(threads, pairs / 64));
+    fn_ = fn;
+    for (int t = 1; t < nt_; ++t) pool_.emplace_back([this, t] { loop(t); });
+  }
+  ~PairWorkers() {
+    quit_.store(true, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_acq_rel);
+    for (auto& th : pool_) th.join();
+  }
+  // runs fn(first, last) over all pairs, the calling thread taking the first range; returns when all ranges are done
+  void run() {
+    done_.store(0, std::memory_order_relaxed);
+    gen_.fetch_add(1, std::memory_order_acq_rel);
+    fn_(0, range_end(0));
+    while (done_.load(std::memory_order_acquire) != nt_ - 1) __builtin_ia32_pause();
+  }
+
+ private:
+  int range_end(int t) const { return static_cast<int>(static_cast<long long>(pairs_) * (t + 1) / nt_); }
+  void loop(int t) {
+    unsigned long long seen = 0;
+    for (;;) {
+      while (gen_.load(std::memory_order_acquire) == seen) __builtin_ia32_pause();
+      ++seen;
+      if (quit_.load(std::memory_order_acquire)) return;
+      fn_(range_end(t - 1), range_end(t));
+      done_.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+  int pairs_, nt_ = 1;
+  std::function<void(int, int)> fn_;
+  std::vector<std::thread> pool_;
+  std::atomic<unsigned long long> gen_{0};
+  std::atomic<int> done_{0};
+  std::atomic<bool> quit_{false};
+};
 
 }  // namespace
 
@@ -339,21 +388,28 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
   std::vector<unsigned char> active(B, 1);
   std::vector<double> qrot(3 * B), qtran(3 * B);
   for (int g = 0; g < B; ++g) solver[g].start(mode, rot + 3 * g, tran + 3 * g, o);
+  // per-pair host work of one lock-step iteration: feed the pair's normal equations to its solver, fetch its next query
+  std::vector<int> newly_done(B, 0);
+  auto feed_range = [&](int first, int last) {
+    for (int g = first; g < last; ++g) {
+      if (!active[g]) continue;
+      sba_normal_eq ne;
+      sba::expand_pack(mode, b->packs_host + 24 * g, &ne);
+      solver[g].feed(ne);
+      if (solver[g].done()) newly_done[g] = 1;
+      for (int a = 0; a < 3; ++a) { qrot[3 * g + a] = solver[g].query_rot()[a]; qtran[3 * g + a] = solver[g].query_tran()[a]; }
+    }
+  };
+  PairWorkers workers(sba::host_threads(), B, feed_range);
+  for (int g = 0; g < B; ++g)
+    for (int a = 0; a < 3; ++a) { qrot[3 * g + a] = solver[g].query_rot()[a]; qtran[3 * g + a] = solver[g].query_tran()[a]; }
   int remaining = B;
   while (remaining > 0) {
-    for (int g = 0; g < B; ++g)
-      for (int a = 0; a < 3; ++a) { qrot[3 * g + a] = solver[g].query_rot()[a]; qtran[3 * g + a] = solver[g].query_tran()[a]; }
     rc = batch_launch(b, mode, depth_mode, qrot.data(), qtran.data(), d1, d2, o.huber_delta, active.data());
     if (rc) return rc;
-    for (int g = 0; g < B; ++g) {
-      if (!active[g]) continue;
-      double pack[24];
-      convert_pack(b, mode, qrot.data() + 3 * g, b->packs_host + 24 * g, pack);
-      sba_normal_eq ne;
-      sba::expand_pack(mode, pack, &ne);
-      solver[g].feed(ne);
-      if (solver[g].done()) { active[g] = 0; --remaining; }
-    }
+    workers.run();
+    for (int g = 0; g < B; ++g)
+      if (newly_done[g]) { newly_done[g] = 0; active[g] = 0; --remaining; }
   }
   int failures = 0;
   for (int g = 0; g < B; ++g) {

@@ -9,6 +9,8 @@ namespace sba {
 
 // Records the message returned by sba_last_error() on this thread and returns `code`.
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// sba_set_host_threads / SBA_HOST_THREADS (>= 1).
+int host_threads();
 
 // Host-side per-sweep state from (rot, tran, depths, delta): SweepParams for the device, and the frame
 // (B, J) that maps the factored kernel's moments to normal equations.

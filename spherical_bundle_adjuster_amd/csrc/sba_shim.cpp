@@ -48,6 +48,7 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 
 namespace sba {
+int host_threads() { return g_host_threads.load(); }
 int set_error(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;

@@ -84,6 +84,17 @@ def test_batch_config_c5_shape_properties():
         err = np.array([np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)])
         assert err.max() < 5e-3
         assert np.allclose(np.linalg.norm(tran, axis=1), 1.0, atol=1e-12)
+        # host threads for the per-pair LM steps (the reference's set_omp): every pair is stepped by exactly one
+        # thread, so nothing may change -- not even the last bit
+        try:
+            for threads in (2, 3, 8):
+                api.set_host_threads(threads)
+                rot_t, tran_t, sums_t, status_t = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
+                                                          options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+                assert np.array_equal(rot_t, rot) and np.array_equal(tran_t, tran) and np.array_equal(status_t, status)
+                assert [s.num_iterations for s in sums_t] == [s.num_iterations for s in sums]
+        finally:
+            api.set_host_threads(1)
 
 
 def test_batch_errors_and_empty():

@@ -54,6 +54,16 @@ def main():
         out["lm_max_iterations"] = max(s.num_iterations for s in sums)
         out["lm_all_converged"] = bool((status == 0).all() and all(s.termination.startswith("CONV") for s in sums))
         out["max_rot_err_rad"] = float(max(np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)))
+        for threads in (4,):        # host threads for the per-pair LM steps (sba_set_host_threads)
+            api.set_host_threads(threads)
+            b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
+                    options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+            t0 = time.perf_counter()
+            rot_t, _, _, _ = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
+                                     options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+            out[f"lm_seconds_{threads}_host_threads"] = time.perf_counter() - t0
+            assert np.array_equal(rot_t, rot)
+        api.set_host_threads(1)
     # equi2cube on device-resident frames: 3840x1920 -> S=600 strip, 6 B per output pixel
     lib = cabi.load_library()
     F, H, W, S = a.frames, 1920, 3840, 600
