@@ -84,13 +84,21 @@ def test_batch_config_c5_shape_properties():
         err = np.array([np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)])
         assert err.max() < 5e-3
         assert np.allclose(np.linalg.norm(tran, axis=1), 1.0, atol=1e-12)
-        # host threads for the per-pair LM steps (the reference's set_omp): every pair is stepped by exactly one
-        # thread, so nothing may change -- not even the last bit
+
+
+def test_batch_solve_host_threads_change_nothing():
+    """Host threads for the per-pair LM steps (sba_set_host_threads, the reference's set_omp; engaged from 64 pairs per
+    thread): every pair is stepped by exactly one thread, so nothing may change -- not even the last bit."""
+    B = 200
+    cs, off, x1, x2, d12 = _make_pairs([1500 + 7 * g for g in range(B)], seed0=9000)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, d12)
+        rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH)
         try:
             for threads in (2, 3, 8):
                 api.set_host_threads(threads)
-                rot_t, tran_t, sums_t, status_t = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
-                                                          options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+                rot_t, tran_t, sums_t, status_t = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH)
                 assert np.array_equal(rot_t, rot) and np.array_equal(tran_t, tran) and np.array_equal(status_t, status)
                 assert [s.num_iterations for s in sums_t] == [s.num_iterations for s in sums]
         finally:
