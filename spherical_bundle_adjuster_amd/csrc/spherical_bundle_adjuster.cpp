@@ -97,8 +97,16 @@ int spherical_bundle_adjuster::do_bundle_adjustment_from_matches(const std::vect
   log_file << expected_roll << ',' << expected_pitch << ',' << expected_yaw << ','
            << init_rot[0] / kPi * 180.0 << ',' << init_rot[1] / kPi * 180.0 << ',' << init_rot[2] / kPi * 180.0 << ','
            << init_tran[0] << ',' << init_tran[1] << ',' << init_tran[2] << ',' << match_size << std::endl;
+  // write_d_circle (.cpp:227-252, :356) draws into an image: outside the accelerated path.  write_log_d (.cpp:357):
+  if (!depth_log_name.empty()) write_log_d(init_d, depth_log_name);
   std::cout << "Done." << std::endl;
   return SBA_OK;
+}
+
+void spherical_bundle_adjuster::write_log_d(const std::vector<std::array<double, 2>>& init_d,
+                                            const std::string& name) const {
+  std::ofstream log_d_file(name + ".txt", std::ios_base::app);
+  for (const auto& d : init_d) log_d_file << d[0] << ',' << d[1] << '\n';
 }
 
 int spherical_bundle_adjuster::solve_problem(sba_lm_options& opt, std::vector<cv::Point3d>& key_point_left_rect,

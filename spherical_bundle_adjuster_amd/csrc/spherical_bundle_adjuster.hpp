@@ -37,6 +37,9 @@ class spherical_bundle_adjuster {
   void set_matcher(matcher_fn fn) { matcher = std::move(fn); }
   void set_device(int hip_device) { device = hip_device; }
   void set_log_path(const std::string& path) { log_path = path; }   // default "log.txt" (.cpp:349)
+  // Per-match depth log (reference write_log_d, .cpp:219-225, called with "log_d" at :357): appends one "d1,d2" line
+  // per match to <name>.txt.  An empty name switches it off (10^7 matches would be a 200 MB text file).
+  void set_depth_log_name(const std::string& name) { depth_log_name = name; }
   // true (default, like the reference): start from the 8-point consensus; false: from the expected values.
   void set_initial_guess(bool on, unsigned long long seed = 0) { use_initial_guess = on; guess_seed = seed; }
   // Everything after the matcher: pixel -> sphere, initial values, three-stage solve, log row.
@@ -55,6 +58,7 @@ class spherical_bundle_adjuster {
 
  private:
   // reference spherical_bundle_adjuster.hpp:37-43 with ceres::Solver::Options -> sba_lm_options
+  void write_log_d(const std::vector<std::array<double, 2>>& init_d, const std::string& name) const;   // .cpp:219-225
   int solve_problem(sba_lm_options& opt, std::vector<cv::Point3d>& key_point_left_rect,
                     std::vector<cv::Point3d>& key_point_right_rect, double* init_rot, double* init_tran,
                     std::vector<std::array<double, 2>>& init_d, int match_num);
@@ -63,6 +67,7 @@ class spherical_bundle_adjuster {
   int num_proc = 1;
   int device = 0;
   std::string log_path = "log.txt";
+  std::string depth_log_name = "log_d";
   matcher_fn matcher;
   bool use_initial_guess = true;
   unsigned long long guess_seed = 0;

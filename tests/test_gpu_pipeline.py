@@ -63,6 +63,9 @@ def test_cli_three_stage_pipeline(oracle, tmp_path):
     # log.txt prints ~6 significant digits
     assert np.abs(got_rot - r2).max() < 2e-6 * max(1, np.abs(r2).max()) + 1e-7
     assert np.abs(got_tran - t2).max() < 2e-5 * max(1, np.abs(t2).max())
+    # log_d.txt: one "d1,d2" line per match with the d-only stage's result (write_log_d, .cpp:219-225, :357)
+    logged = np.loadtxt(tmp_path / "log_d.txt", delimiter=",").reshape(-1, 2)
+    assert logged.shape == (n, 2) and np.abs(logged - d).max() <= 2e-5 * np.abs(d).max()
 
 
 def test_cli_usage_and_errors(tmp_path):
