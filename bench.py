@@ -64,6 +64,22 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def stream_probe(n):
+    """The no-arithmetic streaming ceiling of the sweep kernel's access pattern (tools/stream_probe.hip: the same
+    eight f64 planes read once, 16 B per lane, grid-stride, register prefetch, nt loads), measured in this run on this
+    box as a child process.  Context for roofline.frac; never part of `value`."""
+    import subprocess
+    exe = ROOT / "spherical_bundle_adjuster_amd" / "csrc" / "build" / "stream_probe"
+    if not exe.exists():
+        return None
+    try:
+        r = subprocess.run([str(exe), str(n), "30", "quick"], capture_output=True, text=True, timeout=120)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if r.returncode == 0 and line else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(c, mode, per_match, sample, seconds):
     """Oracle (kind "port"): faithful per-match dual-number functor + per-match trig + Huber corrector, J^T J / J^T e
     accumulated in double (orc_eval_f64 -- the long-double accumulation of the checker is not what is timed), OpenMP
@@ -219,6 +235,16 @@ def main():
             "pcie_inclusive_evals_per_s_if_reuploaded_every_sweep": a.n / (upload_s + elapsed / a.steps),
             "cost": float(pack[22]),
         }
+        if world == 1 and not rehearsal and bytes_per_eval == 64 and a.store == "f64":
+            probe = stream_probe(a.n)
+            if probe:
+                best = max(probe["GBps_1_block_per_cu"], probe["GBps_2_blocks_per_cu"])
+                out["roofline"]["stream_probe"] = {
+                    "GBps_same_grid": probe["GBps_2_blocks_per_cu"], "GBps_best": best,
+                    "sweep_over_probe_same_grid": achieved / probe["GBps_2_blocks_per_cu"],
+                    "sweep_over_probe_best": achieved / best,
+                    "what": "tools/stream_probe.hip, same box, same run: the same 8 planes streamed once with the sweep "
+                            "kernel's access pattern and no residual/Jacobian arithmetic"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c, mode, rt, a.cpu_sample, a.cpu_seconds)
         print(json.dumps(out), flush=True)

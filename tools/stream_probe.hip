@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x)                                                                                       \
@@ -95,13 +96,15 @@ struct Variant { const char* name; Kern k; };
 int main(int argc, char** argv) {
   const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 10000000ull;
   const int launches = argc > 2 ? std::atoi(argv[2]) : 50;
+  const bool quick = argc > 3 && std::string(argv[3]) == "quick";   // bench.py: only the sweep kernel's pattern, one JSON line
   const size_t nvec = n / 2;
   const size_t stagger = 4352;
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  std::printf("# %s, %d CUs, n = %zu matches, %d planes x %.1f MB = %.1f MB per launch\n", prop.name, cus, n, kPlanes,
-              n * 8 / 1e6, n * 8.0 * kPlanes / 1e6);
+  if (!quick)
+    std::printf("# %s, %d CUs, n = %zu matches, %d planes x %.1f MB = %.1f MB per launch\n", prop.name, cus, n, kPlanes,
+                n * 8 / 1e6, n * 8.0 * kPlanes / 1e6);
 
   PlanePtrs pl;
   void* base[kPlanes];
@@ -126,8 +129,10 @@ int main(int argc, char** argv) {
   };
   const int per_cu[] = {1, 2, 3, 4, 8};
   std::vector<unsigned long long> h;
+  double quick_gbps[3] = {0, 0, 0};
   for (const Variant& v : variants)
     for (int bpc : per_cu) {
+      if (quick && (&v != &variants[0] || bpc > 2)) continue;
       const int grid = cus * bpc;
       for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(v.k, dim3(grid), dim3(kBlock), 0, nullptr, pl, nvec, out, clocks);
       CHECK(hipDeviceSynchronize());
@@ -148,6 +153,7 @@ int main(int argc, char** argv) {
       for (int b = 0; b < grid; ++b) { st[b] = (h[2 * b] - first) * 0.01; en[b] = (last - h[2 * b + 1]) * 0.01; }
       std::sort(st.begin(), st.end());
       std::sort(en.begin(), en.end());
+      if (quick) { quick_gbps[bpc] = n * 8.0 * kPlanes / us * 1e-3; continue; }
       std::printf("%-20s %2d blocks/CU  %7.1f us  %6.0f GB/s | in-kernel span %6.1f us; start lag med %4.1f p90 %4.1f max %4.1f us;"
                   " idle-before-end med %4.1f p90 %4.1f max %4.1f us\n",
                   v.name, bpc, us, n * 8.0 * kPlanes / us * 1e-3, (last - first) * 0.01, st[grid / 2], st[grid * 9 / 10],
@@ -167,6 +173,12 @@ int main(int argc, char** argv) {
       }
       std::fflush(stdout);
     }
+  if (quick) {
+    std::printf("{\"n\": %zu, \"bytes_per_launch\": %.0f, \"GBps_1_block_per_cu\": %.1f, \"GBps_2_blocks_per_cu\": %.1f}\n", n,
+                n * 8.0 * kPlanes, quick_gbps[1], quick_gbps[2]);
+    for (int k = 0; k < kPlanes; ++k) CHECK(hipFree(base[k]));
+    return 0;
+  }
   // Is the slow XCD the same from launch to launch?  8 consecutive launches, each with its own clock buffer.
   {
     unsigned long long* clk8;
