@@ -240,8 +240,8 @@ def main():
             if probe:
                 best = max(probe["GBps_1_block_per_cu"], probe["GBps_2_blocks_per_cu"])
                 out["roofline"]["stream_probe"] = {
-                    "GBps_same_grid": probe["GBps_2_blocks_per_cu"], "GBps_best": best,
-                    "sweep_over_probe_same_grid": achieved / probe["GBps_2_blocks_per_cu"],
+                    "GBps_1_block_per_cu": probe["GBps_1_block_per_cu"],
+                    "GBps_2_blocks_per_cu": probe["GBps_2_blocks_per_cu"], "GBps_best": best,
                     "sweep_over_probe_best": achieved / best,
                     "what": "tools/stream_probe.hip, same box, same run: the same 8 planes streamed once with the sweep "
                             "kernel's access pattern and no residual/Jacobian arithmetic"}

@@ -130,9 +130,9 @@ struct sba_problem {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cus = 0;
-  int blocks_per_cu_cap = 2;   // SBA_BLOCKS_PER_CU: resident blocks per CU used.  2 (8 waves/CU) measured best or tied
-                               // in every mode: the register double buffer supplies the memory-level parallelism,
-                               // more waves only add rows to fold (profiles/r01_tune_caps.log)
+  int blocks_per_cu_cap = 0;   // SBA_BLOCKS_PER_CU: resident blocks per CU used; 0 = the per-variant default of grid_for
+                               // (1 or 2: the register double buffer supplies the memory-level parallelism, more
+                               // waves only add rows to fold and finish-time spread, profiles/r01_tune_caps.log)
   int kind = SBA_KERNEL_FACTORED;
   int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
   int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
@@ -233,7 +233,16 @@ int grid_for(sba_problem* p, int mode, int depth_mode, bool loss, int* grid) {
   if (occ == 0) {
     int b = 0;
     SBA_HIP_TRY(sba::sweep_blocks_per_cu(mode, depth_mode, p->store, p->kind, loss, &b));
-    occ = std::max(1, std::min(b, p->blocks_per_cu_cap));
+    // Resident blocks per CU actually used.  Measured per variant at 10^7 matches (profiles/r01_tune_caps.log, re-checked
+    // A/B on one box): the f64 factored kernel streaming 8 planes (R|t with per-match depths: 96.7 / 96.7 / 95.3 us at
+    // one block per CU against 99.6 / 99.0 / 97.4 us at two) and its tran-only form finish tighter with ONE block per
+    // CU -- fewer resident blocks, less finish-time spread between XCDs (profiles/r01_stream_probe.md) -- every other
+    // variant (6 planes, f32 planes, explicit Jacobian) needs the second block to cover its arithmetic.
+    int cap = p->blocks_per_cu_cap;
+    if (cap <= 0)
+      cap = (p->store == SBA_STORE_F64 && p->kind == SBA_KERNEL_FACTORED &&
+             ((mode == SBA_MODE_RT && depth_mode == SBA_DEPTH_PER_MATCH) || mode == SBA_MODE_TRAN)) ? 1 : 2;
+    occ = std::max(1, std::min(b, cap));
   }
   *grid = static_cast<int>(std::min<size_t>(want, static_cast<size_t>(std::min(p->max_grid, p->num_cus * occ))));
   return SBA_OK;
