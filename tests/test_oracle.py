@@ -146,6 +146,44 @@ def test_lm_golden_and_known_answer(oracle):
             assert abs(np.linalg.norm(t) - 1.0) < 1e-14
 
 
+def test_lm_minimiser_vs_independent_numpy_cost_and_scipy(oracle):
+    """The point the LM restatement converges to is a minimiser of the block-wise Huber objective as an INDEPENDENT numpy
+    restatement computes it (cost written from scratch here: Rodrigues via scipy, s = |e|^2 per 3-vector block,
+    rho(s) = s / 2 delta sqrt(s) - delta^2): the central-difference gradient of that cost vanishes there and scipy's
+    BFGS, started from it, cannot lower the cost.  (scipy's own loss='huber' is per component, not per block -- not usable
+    as an oracle)"""
+    from scipy.optimize import minimize
+    from scipy.spatial.transform import Rotation
+
+    c = synthetic.full_rt(3000, seed=91)                       # noise + 5 % outliers: the Huber region is populated
+    delta = 1.0
+
+    def cost(p):
+        R = Rotation.from_rotvec(p[:3]).as_matrix()
+        e = c.d12[:, 1:2] * c.x2 - c.d12[:, 0:1] * (c.x1 @ R.T) + p[3:]
+        s = np.einsum("ij,ij->i", e, e)
+        rho = np.where(s <= delta * delta, s, 2.0 * delta * np.sqrt(np.maximum(s, 1e-300)) - delta * delta)
+        return 0.5 * rho.sum()
+
+    o = oracle.default_options(function_tolerance=1e-16, parameter_tolerance=1e-14, gradient_tolerance=1e-14,
+                               max_num_iterations=200)
+    r, t, s, rc = oracle.lm_solve(2, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12, options=o)
+    assert rc == 0
+    p_lm = np.concatenate([r, t])
+    assert abs(cost(p_lm) - s.final_cost) <= 1e-12 * s.final_cost       # the two cost definitions agree
+    h = 1e-6
+    grad = np.array([(cost(p_lm + h * np.eye(6)[k]) - cost(p_lm - h * np.eye(6)[k])) / (2 * h) for k in range(6)])
+    p0 = np.concatenate([c.rot_init, c.tran_init])
+    grad0 = np.array([(cost(p0 + h * np.eye(6)[k]) - cost(p0 - h * np.eye(6)[k])) / (2 * h) for k in range(6)])
+    assert np.abs(grad).max() <= 1e-6 * np.abs(grad0).max()
+    res = minimize(cost, p_lm, method="BFGS", options={"gtol": 1e-10, "maxiter": 200})
+    assert res.fun >= cost(p_lm) * (1 - 1e-12)
+    assert np.abs(res.x - p_lm).max() < 1e-6
+    # and from the start point scipy reaches the same minimiser (same basin)
+    res0 = minimize(cost, p0, method="BFGS", options={"gtol": 1e-9, "maxiter": 500})
+    assert np.abs(res0.x - p_lm).max() < 1e-5 and abs(res0.fun - cost(p_lm)) <= 1e-9 * cost(p_lm)
+
+
 def test_side_paths_basic(oracle):
     # pixel -> sphere: unit vectors, known pixels
     kp = np.zeros((3, 7), dtype=np.float32)
