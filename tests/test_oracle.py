@@ -229,6 +229,34 @@ def test_depth_stage_oracle(oracle):
     assert rc == 0 and s4.num_successful_steps <= 1 and np.abs(d4 - d3).max() < 1e-3
 
 
+def test_depth_stage_vs_scipy_per_match(oracle):
+    """Run to tight tolerances, the one global bounded problem (.cpp:1004-1063) must land on the per-match optima:
+    each match's two depths minimise its own five residuals subject to d >= 0 -- checked with scipy's bounded
+    least_squares on independently written residuals (Rodrigues via scipy)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+
+    c = synthetic.full_rt(60, seed=8)                              # noise + outliers: some depths end on the bound
+    o = oracle.default_options(function_tolerance=1e-16, parameter_tolerance=1e-13, gradient_tolerance=1e-13,
+                               max_num_iterations=500)
+    d, s, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, np.full((60, 2), 3.0), options=o)
+    assert rc == 0
+    R = Rotation.from_rotvec(c.rot_init).as_matrix()
+    on_bound = 0
+    for i in range(60):
+        q = R @ c.x1[i]
+
+        def res(dd):
+            return np.concatenate([dd[1] * c.x2[i] - dd[0] * q + c.tran_init, [np.exp(-dd[0]), np.exp(-dd[1])]])
+        best = min((least_squares(res, start, bounds=(0.0, np.inf), xtol=1e-15, ftol=1e-15, gtol=1e-15)
+                    for start in ([3.0, 3.0], np.maximum(d[i], 1e-3))), key=lambda r_: r_.cost)
+        mine = 0.5 * np.sum(res(d[i]) ** 2)
+        assert mine <= best.cost * (1 + 1e-9) + 1e-15, (i, mine, best.cost)   # never worse than scipy's optimum
+        assert np.abs(d[i] - best.x).max() <= 1e-5 * max(1.0, np.abs(best.x).max()), (i, d[i], best.x)
+        on_bound += int((d[i] == 0.0).any())
+    assert (d >= 0).all()
+
+
 def test_matcher_coordinate_maps_oracle(oracle):
     """rotate_keypoint / crop_rotated_image / cube2equi_pixel restatements: consistency properties."""
     H, W, S = 480, 960, 120
