@@ -107,24 +107,12 @@ int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, cons
     SBA_TRY_HIP(hipStreamSynchronize(b->stream));
     return SBA_OK;
   }
-  // A stream query every so often turns a device fault into an error instead of an endless spin.
   const unsigned long long seq = ++b->seq;
   SBA_TRY_HIP(sba::launch_batch_step(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
                                      b->params_dev, b->frames_dev, b->desc_dev, B, b->bpp, b->partials, b->packs_dev,
                                      b->packs_host_dev, seq, b->stream));
-  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B);
-  for (unsigned long spins = 0; *flag != seq; ++spins) {
-    if ((spins & 0xfff) == 0xfff) {
-      const hipError_t q = hipStreamQuery(b->stream);
-      if (q != hipSuccess && q != hipErrorNotReady)
-        return sba::set_error(SBA_ERR_HIP, "batched sweep failed on the device: %s", hipGetErrorString(q));
-      if (q == hipSuccess && *flag != seq)
-        return sba::set_error(SBA_ERR_HIP, "batched sweep finished without publishing its result");
-    }
-    __builtin_ia32_pause();
-  }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  return SBA_OK;
+  return sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B), seq, b->stream,
+                                "batched sweep");
 }
 
 // The packs arrive in the SBA_PACK_* layout (the finalize kernel converts the factored kernel's moments on the device).

@@ -11,6 +11,11 @@ namespace sba {
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // sba_set_host_threads / SBA_HOST_THREADS (>= 1).
 int host_threads();
+// Host side of the publish protocol: a kernel stores its results into mapped pinned host memory, fences at system
+// scope, then stores `seq` into `*flag`; the host polls that word.  A stream query every 4096 spins turns a device
+// fault into an error instead of an endless spin.  `what` names the work in the error text.
+int wait_for_sequence(const volatile unsigned long long* flag, unsigned long long seq, hipStream_t stream,
+                      const char* what);
 
 // Host-side per-sweep state from (rot, tran, depths, delta): SweepParams for the device, and the frame
 // (B, J) that maps the factored kernel's moments to normal equations.

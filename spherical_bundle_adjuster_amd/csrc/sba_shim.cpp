@@ -49,6 +49,20 @@ int fail(int code, const char* fmt, ...) {
 
 namespace sba {
 int host_threads() { return g_host_threads.load(); }
+int wait_for_sequence(const volatile unsigned long long* flag, unsigned long long seq, hipStream_t stream,
+                      const char* what) {
+  for (unsigned long spins = 0; *flag != seq; ++spins) {
+    if ((spins & 0xfff) == 0xfff) {
+      const hipError_t q = hipStreamQuery(stream);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return set_error(SBA_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
+      if (q == hipSuccess && *flag != seq) return set_error(SBA_ERR_HIP, "%s finished without publishing its result", what);
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return SBA_OK;
+}
 int set_error(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -382,20 +396,9 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
 // Wait for the reduced pack on the host; the factored kernel's moments are mapped to the SBA_PACK_* layout.
 int fetch_pack_raw(sba_problem* p, double raw[SBA_PACK_SIZE]) {
   if (p->published) {
-    // The kernel stores the 24 doubles, fences at system scope, then stores the sequence number: poll it.
-    // A stream query every so often turns a device fault into an error instead of an endless spin.
-    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24);
-    for (unsigned long spins = 0; *flag != p->seq; ++spins) {
-      if ((spins & 0xfff) == 0xfff) {
-        const hipError_t q = hipStreamQuery(p->stream);
-        if (q != hipSuccess && q != hipErrorNotReady)
-          return fail(SBA_ERR_HIP, "sweep failed on the device: %s", hipGetErrorString(q));
-        if (q == hipSuccess && *flag != p->seq)
-          return fail(SBA_ERR_HIP, "sweep finished without publishing its result");
-      }
-      __builtin_ia32_pause();
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), p->seq,
+                                          p->stream, "sweep");
+    if (rc) return rc;
     if (p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
       return fail(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's pack");
   } else {
@@ -1006,17 +1009,9 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
       const unsigned long long seq = ++p->seq;
       SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
                                          out_dev, p->pack_host_dev, seq, -1, p->stream));
-      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24);
-      for (unsigned long spins = 0; *flag != seq; ++spins) {
-        if ((spins & 0xfff) == 0xfff) {
-          const hipError_t q = hipStreamQuery(p->stream);
-          if (q != hipSuccess && q != hipErrorNotReady)
-            return fail(SBA_ERR_HIP, "d-only pass failed on the device: %s", hipGetErrorString(q));
-          if (q == hipSuccess && *flag != seq) return fail(SBA_ERR_HIP, "d-only pass finished without publishing its result");
-        }
-        __builtin_ia32_pause();
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), seq,
+                                            p->stream, "d-only pass");
+      if (rc) return rc;
     } else {
       SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
                                          out_dev, nullptr, 0, -1, p->stream));
