@@ -1,0 +1,101 @@
+// The problem handle behind the C-ABI and the helpers shared by the translation units that implement it:
+//   sba_shim.cpp       errors, handle life cycle, uploads, sweeps, eval / solve entry points, side entry points
+//   sba_transport.cpp  multi-GPU transports: RCCL (bound at run time), direct peer exchange, user hook; pack all-reduce
+//   sba_stages.cpp     d-only stage and 8-point initial guess entry points
+// Internal: nothing here is exported from the library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/sba_hip.h"
+#include "sba_device.hpp"
+#include "sba_internal.hpp"
+
+// ---- the handle ---------------------------------------------------------------------------------
+struct sba_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 0;
+  int blocks_per_cu_cap = 0;   // SBA_BLOCKS_PER_CU: resident blocks per CU used; 0 = the per-variant default of grid_for
+                               // (1 or 2: the register double buffer supplies the memory-level parallelism, more
+                               // waves only add rows to fold and finish-time spread, profiles/r01_tune_caps.log)
+  int kind = SBA_KERNEL_FACTORED;
+  int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
+  int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
+  double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
+  size_t epi_scratch_elems = 0;
+  double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
+  int last_mode = 0;
+
+  size_t n = 0;
+  int store = SBA_STORE_F64;
+  bool has_d12 = false;
+  bool uploaded = false;
+  size_t plane_elems = 0;     // allocated elements per plane (n rounded up to a whole vector)
+  void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* dplane[2] = {nullptr, nullptr};
+  void* plane_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // hipMalloc'ed blocks
+  size_t plane_stagger = 4352; // SBA_PLANE_STAGGER: plane k starts k * 4352 B (17 x 256 B) into its allocation, so equal
+                               // element indices of the 8 streams differ in their low address bits (measured 0-4 %
+                               // faster with f64 planes, 3-5 % with f32 planes; never slower)
+
+  double* partials = nullptr;  // [max_grid][24]
+  int max_grid = 0;
+  double* pack_dev = nullptr;  // 32 doubles
+  double* pack_host = nullptr; // pinned + mapped, 32 doubles ([24] = sequence number published by the kernel)
+  double* pack_host_dev = nullptr;  // device-visible address of pack_host
+  unsigned int* ticket = nullptr;   // arrival counter of the fused final reduction
+  unsigned long long seq = 0;       // sweeps launched with host publication
+  int fused_mode = 0;               // SBA_FUSED: 0 (default) never, 1 always, 2 only for grids <= kFusedMaxGrid
+  bool publish = true;              // SBA_PUBLISH=0: D2H copy + stream sync instead of kernel-side publication
+  bool published = false;           // the last enqueued sweep publishes to pack_host itself
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  // direct peer exchange (IPC-mapped inboxes, sba_problem_peer_*)
+  double* inbox = nullptr;
+  sba::PeerInboxes peers{};
+  void* peer_opened[sba::kMaxPeers] = {nullptr};
+  bool peer_ready = false;
+  unsigned long long xseq = 0;
+  unsigned long long peer_spin_limit = 20000000ull;   // bounded wait (tens of seconds) before SBA_ERR_COMM
+
+  sba_allreduce_fn hook = nullptr;
+  void* hook_user = nullptr;
+  void* comm = nullptr;        // ncclComm_t
+  int nranks = 1;
+  int shard_rank = 0, shard_count = 1;   // which shard of the correspondences this problem holds (d-only stage)
+};
+
+namespace sba {
+namespace shim {
+
+// ---- RCCL, bound at run time -------------------------------------------------------------------
+// The library is dlopen'ed instead of linked so that a process which already carries an RCCL
+// (torch ships its own librccl.so.1) keeps exactly one copy.
+struct Rccl {
+  typedef struct { char internal[SBA_COMM_ID_BYTES]; } UniqueId;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* handle = nullptr;
+  bool ok = false;
+  std::string why;
+};
+Rccl& rccl();
+constexpr int kNcclFloat64 = 8;  // ncclDouble
+constexpr int kNcclSum = 0;      // ncclSum
+
+inline bool is_collective(const sba_problem* p) { return p->comm != nullptr || p->hook != nullptr || p->peer_ready; }
+
+// sba_transport.cpp
+int allreduce_pack(sba_problem* p);                                  // p->pack_dev (24 doubles), then hand-over to the host
+int allreduce_buffer(sba_problem* p, double* dev, size_t count);     // any device buffer, count a multiple of 24
+// sba_shim.cpp
+int fetch_pack_raw(sba_problem* p, double raw[SBA_PACK_SIZE]);       // wait for the pack handed over by the last sweep / pass
+
+}  // namespace shim
+}  // namespace sba

@@ -1,4 +1,5 @@
-// C-ABI shim (include/sba_hip.h) over the HIP kernels: handles, uploads, sweeps, RCCL.
+// C-ABI shim (include/sba_hip.h) over the HIP kernels: errors, handle life cycle, uploads, sweeps, eval / solve entry
+// points and the side entry points.  Transports: sba_transport.cpp; d-only stage and initial guess: sba_stages.cpp.
 // Host code only; compiled with hipcc for the HIP runtime API.  No CPU fallback exists here:
 // every compute entry point needs a HIP device and fails with SBA_ERR_NO_DEVICE otherwise.
 #include "../../include/sba_hip.h"
@@ -21,6 +22,7 @@
 #include "sba_device.hpp"
 #include "sba_epipolar.hpp"
 #include "sba_internal.hpp"
+#include "sba_problem.hpp"
 #include "sba_lm.hpp"
 #include "sba_rotation.hpp"
 
@@ -80,6 +82,11 @@ void make_sweep_params(size_t n, int depth_mode, const double rot[3], const doub
 }  // namespace sba
 
 namespace {
+using sba::shim::allreduce_pack;
+using sba::shim::kNcclFloat64;
+using sba::shim::kNcclSum;
+using sba::shim::Rccl;
+using sba::shim::rccl;
 
 #define SBA_HIP_TRY(expr)                                                                   \
   do {                                                                                      \
@@ -89,110 +96,8 @@ namespace {
                   __LINE__);                                                                \
   } while (0)
 
-// ---- RCCL, bound at run time -------------------------------------------------------------------
-// The library is dlopen'ed instead of linked so that a process which already carries an RCCL
-// (torch ships its own librccl.so.1) keeps exactly one copy.
-struct Rccl {
-  typedef struct { char internal[SBA_COMM_ID_BYTES]; } UniqueId;
-  int (*GetUniqueId)(UniqueId*) = nullptr;
-  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-  void* handle = nullptr;
-  bool ok = false;
-  std::string why;
-};
-
-Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* nm : names) {
-    r.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
-    if (r.handle) break;
-  }
-  if (!r.handle)
-    for (const char* nm : names) {
-      r.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-      if (r.handle) break;
-    }
-  if (!r.handle) {
-    r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
-    return r;
-  }
-  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
-  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
-  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
-  r.GetErrorString =
-      reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
-  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
-  if (!r.ok) r.why = "librccl is missing ncclGetUniqueId/CommInitRank/CommDestroy/AllReduce";
-  return r;
-}
-constexpr int kNcclFloat64 = 8;  // ncclDouble
-constexpr int kNcclSum = 0;      // ncclSum
-
 }  // namespace
 
-// ---- the handle ---------------------------------------------------------------------------------
-struct sba_problem {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  int num_cus = 0;
-  int blocks_per_cu_cap = 0;   // SBA_BLOCKS_PER_CU: resident blocks per CU used; 0 = the per-variant default of grid_for
-                               // (1 or 2: the register double buffer supplies the memory-level parallelism, more
-                               // waves only add rows to fold and finish-time spread, profiles/r01_tune_caps.log)
-  int kind = SBA_KERNEL_FACTORED;
-  int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
-  int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
-  double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
-  size_t epi_scratch_elems = 0;
-  double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
-  int last_mode = 0;
-
-  size_t n = 0;
-  int store = SBA_STORE_F64;
-  bool has_d12 = false;
-  bool uploaded = false;
-  size_t plane_elems = 0;     // allocated elements per plane (n rounded up to a whole vector)
-  void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  double* dplane[2] = {nullptr, nullptr};
-  void* plane_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // hipMalloc'ed blocks
-  size_t plane_stagger = 4352; // SBA_PLANE_STAGGER: plane k starts k * 4352 B (17 x 256 B) into its allocation, so equal
-                               // element indices of the 8 streams differ in their low address bits (measured 0-4 %
-                               // faster with f64 planes, 3-5 % with f32 planes; never slower)
-
-  double* partials = nullptr;  // [max_grid][24]
-  int max_grid = 0;
-  double* pack_dev = nullptr;  // 32 doubles
-  double* pack_host = nullptr; // pinned + mapped, 32 doubles ([24] = sequence number published by the kernel)
-  double* pack_host_dev = nullptr;  // device-visible address of pack_host
-  unsigned int* ticket = nullptr;   // arrival counter of the fused final reduction
-  unsigned long long seq = 0;       // sweeps launched with host publication
-  int fused_mode = 0;               // SBA_FUSED: 0 (default) never, 1 always, 2 only for grids <= kFusedMaxGrid
-  bool publish = true;              // SBA_PUBLISH=0: D2H copy + stream sync instead of kernel-side publication
-  bool published = false;           // the last enqueued sweep publishes to pack_host itself
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-  // direct peer exchange (IPC-mapped inboxes, sba_problem_peer_*)
-  double* inbox = nullptr;
-  sba::PeerInboxes peers{};
-  void* peer_opened[sba::kMaxPeers] = {nullptr};
-  bool peer_ready = false;
-  unsigned long long xseq = 0;
-  unsigned long long peer_spin_limit = 20000000ull;   // bounded wait (tens of seconds) before SBA_ERR_COMM
-
-  sba_allreduce_fn hook = nullptr;
-  void* hook_user = nullptr;
-  void* comm = nullptr;        // ncclComm_t
-  int nranks = 1;
-  int shard_rank = 0, shard_count = 1;   // which shard of the correspondences this problem holds (d-only stage)
-};
 
 namespace {
 
@@ -288,61 +193,6 @@ void make_frame(sba_problem* p, int mode, const double rot[3]) {
 }
 
 // Enqueue one sweep + finalize (+ all-reduce) on the problem's stream; pack_dev holds the result.
-// SUM all-reduce of the 24-double pack in p->pack_dev over the attached transport (RCCL or the user hook), then the
-// one-wave publish kernel hands the result to the host like the single-GPU path does itself.
-int allreduce_pack(sba_problem* p) {
-  if (p->peer_ready) {   // direct peer stores + rank-ordered local sum; the exchanging wave publishes to the host
-    p->published = p->publish;
-    if (p->publish) ++p->seq;
-    SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev,
-                                          p->publish ? p->pack_host_dev : nullptr, p->seq, p->peer_spin_limit,
-                                          p->stream));
-    return SBA_OK;
-  }
-  if (p->comm) {
-    Rccl& r = rccl();
-    const int rc = r.AllReduce(p->pack_dev, p->pack_dev, SBA_PACK_SIZE, kNcclFloat64, kNcclSum,
-                               p->comm, p->stream);
-    if (rc != 0)
-      return fail(SBA_ERR_COMM, "ncclAllReduce failed: %s",
-                  r.GetErrorString ? r.GetErrorString(rc) : "?");
-  } else if (p->hook) {
-    const int rc = p->hook(p->pack_dev, SBA_PACK_SIZE, p->stream, p->hook_user);
-    if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
-  }
-  p->published = false;
-  if (p->publish) {
-    SBA_HIP_TRY(sba::launch_publish(p->pack_dev, p->pack_host_dev, ++p->seq, p->stream));
-    p->published = true;
-  }
-  return SBA_OK;
-}
-
-// SUM all-reduce of `count` doubles at `dev` (count a multiple of 24) over the attached transport, in stream order.
-// Over the peer transport the buffer travels as count / 24 back-to-back exchanges of the 24-double inbox slots; the
-// last one publishes to the host so that a timeout shows in word 25 of the host pack (checked by the caller).
-int allreduce_buffer(sba_problem* p, double* dev, size_t count) {
-  if (p->peer_ready) {
-    if (count % SBA_PACK_SIZE != 0) return fail(SBA_ERR_INVALID_ARG, "peer all-reduce needs a multiple of 24 doubles");
-    for (size_t off = 0; off < count; off += SBA_PACK_SIZE) {
-      const bool last = off + SBA_PACK_SIZE >= count;
-      SBA_HIP_TRY(sba::launch_peer_exchange(dev + off, p->peers, ++p->xseq, dev + off,
-                                            last ? p->pack_host_dev : nullptr, last ? ++p->seq : 0,
-                                            p->peer_spin_limit, p->stream));
-    }
-    return SBA_OK;
-  }
-  if (p->comm) {
-    Rccl& r = rccl();
-    const int rc = r.AllReduce(dev, dev, count, kNcclFloat64, kNcclSum, p->comm, p->stream);
-    if (rc != 0) return fail(SBA_ERR_COMM, "ncclAllReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
-  } else if (p->hook) {
-    const int rc = p->hook(dev, count, p->stream, p->hook_user);
-    if (rc != 0) return fail(SBA_ERR_COMM, "all-reduce hook returned %d", rc);
-  }
-  return SBA_OK;
-}
-
 int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepParams& prm) {
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) {
@@ -393,6 +243,10 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
   return SBA_OK;
 }
 
+}  // namespace
+
+namespace sba {
+namespace shim {
 // Wait for the reduced pack on the host; the factored kernel's moments are mapped to the SBA_PACK_* layout.
 int fetch_pack_raw(sba_problem* p, double raw[SBA_PACK_SIZE]) {
   if (p->published) {
@@ -409,6 +263,12 @@ int fetch_pack_raw(sba_problem* p, double raw[SBA_PACK_SIZE]) {
   std::memcpy(raw, p->pack_host, SBA_PACK_SIZE * sizeof(double));
   return SBA_OK;
 }
+
+}  // namespace shim
+}  // namespace sba
+
+namespace {
+using sba::shim::fetch_pack_raw;
 
 // ... and map the factored kernel's moments to the SBA_PACK_* layout.
 int fetch_pack(sba_problem* p, double pack[SBA_PACK_SIZE]) {
@@ -771,370 +631,6 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
   if (eval_rc != SBA_OK) return eval_rc;  // message already set by the failing eval
   if (lm_rc != SBA_OK) return fail(lm_rc, "LM failed: non-finite or singular normal equations");
   return SBA_OK;
-}
-
-// ---- multi-GPU -----------------------------------------------------------------------------------
-int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]) {
-  if (!id) return fail(SBA_ERR_INVALID_ARG, "id is null");
-  Rccl& r = rccl();
-  if (!r.ok) return fail(SBA_ERR_COMM, "%s", r.why.c_str());
-  Rccl::UniqueId u;
-  const int rc = r.GetUniqueId(&u);
-  if (rc != 0) return fail(SBA_ERR_COMM, "ncclGetUniqueId failed (%d)", rc);
-  std::memcpy(id, u.internal, SBA_COMM_ID_BYTES);
-  return SBA_OK;
-}
-
-int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]) {
-  if (!p || !id) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SBA_ERR_INVALID_ARG, "bad rank %d/%d", rank, nranks);
-  Rccl& r = rccl();
-  if (!r.ok) return fail(SBA_ERR_COMM, "%s", r.why.c_str());
-  SBA_HIP_TRY(hipSetDevice(p->device));
-  Rccl::UniqueId u;
-  std::memcpy(u.internal, id, SBA_COMM_ID_BYTES);
-  void* comm = nullptr;
-  const int rc = r.CommInitRank(&comm, nranks, u, rank);
-  if (rc != 0)
-    return fail(SBA_ERR_COMM, "ncclCommInitRank failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
-  if (p->comm) r.CommDestroy(p->comm);
-  p->comm = comm;
-  p->nranks = nranks;
-  p->shard_rank = rank;
-  p->shard_count = nranks;
-  return SBA_OK;
-}
-
-// ---- direct peer exchange ---------------------------------------------------------------------------------------
-int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SBA_PEER_HANDLE_BYTES]) {
-  if (!p || !handle) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  if (nranks < 1 || nranks > sba::kMaxPeers || rank < 0 || rank >= nranks)
-    return fail(SBA_ERR_INVALID_ARG, "bad rank %d/%d (at most %d ranks)", rank, nranks, sba::kMaxPeers);
-  static_assert(sizeof(hipIpcMemHandle_t) == SBA_PEER_HANDLE_BYTES, "IPC handle size");
-  SBA_HIP_TRY(hipSetDevice(p->device));
-  (void)sba_problem_peer_disable(p);
-  const size_t bytes = sba::kInboxDoubles * sizeof(double);
-  // fine-grained / uncached device memory: remote stores and local polls must not sit in a non-coherent cache
-  void* mem = nullptr;
-  if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) != hipSuccess) {
-    (void)hipGetLastError();
-    if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
-      SBA_HIP_TRY(hipMalloc(&mem, bytes));
-    }
-  }
-  p->inbox = static_cast<double*>(mem);
-  SBA_HIP_TRY(hipMemset(p->inbox, 0, bytes));
-  SBA_HIP_TRY(hipDeviceSynchronize());
-  hipIpcMemHandle_t h;
-  const hipError_t e = hipIpcGetMemHandle(&h, p->inbox);
-  if (e != hipSuccess) {
-    (void)hipFree(p->inbox);
-    p->inbox = nullptr;
-    return fail(SBA_ERR_COMM, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
-  }
-  std::memcpy(handle, &h, SBA_PEER_HANDLE_BYTES);
-  p->peers.nranks = nranks;
-  p->peers.rank = rank;
-  p->shard_rank = rank;
-  p->shard_count = nranks;
-  return SBA_OK;
-}
-
-int sba_problem_peer_connect(sba_problem* p, const char* handles) {
-  if (!p || !handles) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  if (!p->inbox) return fail(SBA_ERR_INVALID_ARG, "call sba_problem_peer_export first");
-  SBA_HIP_TRY(hipSetDevice(p->device));
-  for (int r = 0; r < p->peers.nranks; ++r) {
-    if (r == p->peers.rank) { p->peers.inbox[r] = p->inbox; continue; }
-    hipIpcMemHandle_t h;
-    std::memcpy(&h, handles + static_cast<size_t>(r) * SBA_PEER_HANDLE_BYTES, SBA_PEER_HANDLE_BYTES);
-    void* ptr = nullptr;
-    const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) {
-      (void)sba_problem_peer_disable(p);
-      return fail(SBA_ERR_COMM, "hipIpcOpenMemHandle(rank %d) failed: %s", r, hipGetErrorString(e));
-    }
-    p->peer_opened[r] = ptr;
-    p->peers.inbox[r] = static_cast<double*>(ptr);
-  }
-  p->xseq = 0;
-  p->peer_ready = true;
-  return SBA_OK;
-}
-
-int sba_problem_peer_disable(sba_problem* p) {
-  if (!p) return SBA_OK;
-  (void)hipSetDevice(p->device);
-  if (p->stream) (void)hipStreamSynchronize(p->stream);
-  for (auto& o : p->peer_opened) {
-    if (o) (void)hipIpcCloseMemHandle(o);
-    o = nullptr;
-  }
-  if (p->inbox) (void)hipFree(p->inbox);
-  p->inbox = nullptr;
-  p->peer_ready = false;
-  return SBA_OK;
-}
-
-// `rounds` exchanges of a known pack (rank + 1 in every slot, plus the round number): every rank must obtain
-// nranks (nranks + 1) / 2 + nranks * round.  *ok = 1 on success.  All ranks must call it together.
-int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok) {
-  if (!p || !ok) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  *ok = 0;
-  if (!p->peer_ready) return fail(SBA_ERR_INVALID_ARG, "peer exchange is not connected");
-  SBA_HIP_TRY(hipSetDevice(p->device));
-  const int n = p->peers.nranks;
-  const unsigned long long limit = p->peer_spin_limit;
-  p->peer_spin_limit = 3000000ull;   // a few seconds at most per round in the self-test
-  int good = 1;
-  for (int k = 0; k < rounds && good; ++k) {
-    double v[32];
-    for (int i = 0; i < 32; ++i) v[i] = static_cast<double>(p->peers.rank + 1 + k);
-    SBA_HIP_TRY(hipMemcpyAsync(p->pack_dev, v, 24 * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    ++p->seq;
-    p->published = true;
-    SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev, p->pack_host_dev, p->seq,
-                                          p->peer_spin_limit, p->stream));
-    double got[24];
-    const int rc = fetch_pack_raw(p, got);
-    if (rc != SBA_OK) { good = 0; break; }
-    const double want = 0.5 * n * (n + 1) + static_cast<double>(n) * k;
-    for (int i = 0; i < 24; ++i)
-      if (got[i] != want) good = 0;
-  }
-  p->peer_spin_limit = limit;
-  *ok = good;
-  return SBA_OK;
-}
-
-int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user) {
-  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
-  p->hook = fn;
-  p->hook_user = user;
-  return SBA_OK;
-}
-
-int sba_problem_set_shard(sba_problem* p, int rank, int nranks) {
-  if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
-  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SBA_ERR_INVALID_ARG, "bad shard %d/%d", rank, nranks);
-  p->shard_rank = rank;
-  p->shard_count = nranks;
-  return SBA_OK;
-}
-
-int sba_problem_pack_device_ptr(sba_problem* p, void** dev_ptr) {
-  if (!p || !dev_ptr) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  *dev_ptr = p->pack_dev;
-  return SBA_OK;
-}
-
-// ---- callers / data formats either side of the path ----------------------------------------------
-int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
-                             double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary) {
-  if (!p || !rot || !tran) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
-  if (!p->has_d12 && p->n > 0) return fail(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
-  // Sharded problem: the six global reductions of every pass are all-reduced over the attached transport (the
-  // maximum travels as one slot per rank, so at most 16 shards), and every rank replays the same step logic.
-  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
-  if (collective && (p->shard_count < 1 || p->shard_count > 16 || p->shard_rank < 0 || p->shard_rank >= p->shard_count))
-    return fail(SBA_ERR_UNSUPPORTED, "d-only stage over a transport needs 1..16 shards (sba_problem_set_shard); have %d/%d",
-                p->shard_rank, p->shard_count);
-  SBA_HIP_TRY(hipSetDevice(p->device));
-  sba_lm_options o;
-  if (opt) o = *opt; else sba::lm_default_options(&o);
-  sba_lm_summary local;
-  sba_lm_summary* sum = summary ? summary : &local;
-  std::memset(sum, 0, sizeof(*sum));
-  const auto t_start = std::chrono::steady_clock::now();
-  const size_t n = p->n, elems = std::max<size_t>(p->plane_elems, 2);
-
-  // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, 8 results
-  sba::DeviceBuffer work_buf, partials_buf, out_buf;
-  SBA_HIP_TRY(work_buf.alloc(6 * elems * sizeof(double)));
-  double* work = work_buf.as<double>();
-  double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
-         *dg2 = work + 5 * elems;
-  // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
-  int& occ = p->depth_occ[p->store];
-  if (occ == 0) {
-    SBA_HIP_TRY(sba::depth_blocks_per_cu(p->store, &occ));
-    occ = std::max(1, occ);
-  }
-  int cap = 8;
-  if (const char* env = std::getenv("SBA_DEPTH_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) cap = v; }
-  const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256,
-                                                     static_cast<size_t>(p->num_cus) * std::max(1, std::min(occ, cap))));
-  SBA_HIP_TRY(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
-  SBA_HIP_TRY(out_buf.alloc(8 * sizeof(double)));
-  double *partials = partials_buf.as<double>(), *out_dev = out_buf.as<double>();
-
-  sba::Planes pl;
-  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
-  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
-  sba::DepthParams prm;
-  double G[27];
-  sba::rotation_and_derivatives(rot, prm.R, G);
-  for (int i = 0; i < 3; ++i) prm.t[i] = tran[i];
-  prm.lambda = lambda; prm.c = c;
-  prm.min_diagonal = o.min_lm_diagonal; prm.max_diagonal = o.max_lm_diagonal;
-  prm.jacobi_scaling = o.jacobi_scaling; prm.pad_ = 0; prm.n = n;
-
-  double* cur1 = p->dplane[0];
-  double* cur2 = p->dplane[1];
-  double radius = o.initial_trust_region_radius, nu = 2.0;
-  bool reuse = false, first = true;
-  int invalid = 0, rc_final = SBA_OK;
-  double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto step = [&]() -> int {   // one device pass at the current depths
-    prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
-    if (collective) {
-      SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
-                                         p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
-      int rc = allreduce_pack(p);
-      if (rc) return rc;
-      double raw[SBA_PACK_SIZE];
-      rc = fetch_pack_raw(p, raw);
-      if (rc) return rc;
-      for (int k = 0; k < 5; ++k) out[k] = raw[k];
-      out[5] = 0.0;
-      for (int r = 0; r < p->shard_count; ++r) out[5] = std::max(out[5], raw[8 + r]);
-      sum->num_evaluations++;
-      first = false;
-      return SBA_OK;
-    }
-    if (p->publish) {
-      // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
-      const unsigned long long seq = ++p->seq;
-      SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
-                                         out_dev, p->pack_host_dev, seq, -1, p->stream));
-      const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), seq,
-                                            p->stream, "d-only pass");
-      if (rc) return rc;
-    } else {
-      SBA_HIP_TRY(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
-                                         out_dev, nullptr, 0, -1, p->stream));
-      SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-      SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-    }
-    std::memcpy(out, p->pack_host, sizeof(out));
-    sum->num_evaluations++;
-    first = false;
-    return SBA_OK;
-  };
-  auto finish = [&](int term, double cost, double gmax) {
-    sum->termination = term; sum->final_cost = cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius;
-    sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  };
-
-  for (int it = 1;; ++it) {
-    int rc = step();
-    if (rc) return rc;
-    const double cost = out[0], model = out[1], cand_cost = out[2], gmax = out[5];
-    if (it == 1) {
-      sum->initial_cost = cost;
-      if (!std::isfinite(cost)) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
-    }
-    // Ceres checks the gradient tolerance after every successful step (and at iteration 0): the gradient at the
-    // current point arrives with this pass.
-    if (!reuse && gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cost, gmax); break; }
-    if (it > o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cost, gmax); break; }
-    if (radius < o.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, cost, gmax); break; }
-    sum->num_iterations = it;
-    if (!(model > 0.0)) {
-      if (++invalid >= 5) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
-      radius /= nu; nu *= 2.0; reuse = true;
-      continue;
-    }
-    invalid = 0;
-    if (std::sqrt(out[3]) <= o.parameter_tolerance * (std::sqrt(out[4]) + o.parameter_tolerance)) {
-      finish(SBA_TERM_CONVERGENCE_PARAMETER, cost, gmax); break;
-    }
-    const double change = cost - cand_cost;
-    if (std::fabs(change) <= o.function_tolerance * cost) { finish(SBA_TERM_CONVERGENCE_FUNCTION, cost, gmax); break; }
-    const double quality = change / model;
-    if (quality > o.min_relative_decrease) {
-      std::swap(cur1, c1); std::swap(cur2, c2);     // the candidate planes become the current depths
-      sum->num_successful_steps++;
-      const double q = 2.0 * quality - 1.0;
-      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
-      nu = 2.0; reuse = false;
-    } else {
-      radius /= nu; nu *= 2.0; reuse = true;
-    }
-  }
-  // the problem's depth planes must end up holding the result
-  if (cur1 != p->dplane[0]) {
-    SBA_HIP_TRY(hipMemcpyAsync(p->dplane[0], cur1, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-    SBA_HIP_TRY(hipMemcpyAsync(p->dplane[1], cur2, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-  }
-  if (d12_out && n > 0) {
-    sba::DeviceBuffer aos;
-    SBA_HIP_TRY(aos.alloc(2 * n * sizeof(double)));
-    SBA_HIP_TRY(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos.as<double>(), p->stream));
-    SBA_HIP_TRY(hipMemcpyAsync(d12_out, aos.ptr, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-  }
-  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-  if (rc_final != SBA_OK) return fail(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
-  return SBA_OK;
-}
-
-// ---- 8-point initial guess (reference .cpp:47-181) -------------------------------------------------------
-int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
-  if (!p || !groups) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
-  SBA_HIP_TRY(hipSetDevice(p->device));
-  const size_t nquad = (p->n + 3) / 4;
-  const int grid = static_cast<int>(std::min<size_t>((nquad + 63) / 64, static_cast<size_t>(p->num_cus) * 4));
-  const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
-  // scratch (block partials + the groups) lives in the handle: allocating 23 MB per call cost more than the pass
-  const size_t need = (static_cast<size_t>(std::max(grid, 1)) + 1) * gsz;
-  if (p->epi_scratch_elems < need) {
-    if (p->epi_scratch) SBA_HIP_TRY(hipFree(p->epi_scratch));
-    p->epi_scratch = nullptr; p->epi_scratch_elems = 0;
-    SBA_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->epi_scratch), need * sizeof(double)));
-    p->epi_scratch_elems = need;
-  }
-  double *groups_dev = p->epi_scratch, *partials = p->epi_scratch + gsz;
-  sba::Planes pl;
-  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
-  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
-  SBA_HIP_TRY(sba::launch_epipolar_moments(p->store, pl, p->n, partials, grid, groups_dev, p->stream));
-  // Sharded problem: group g of the whole problem is the union of every shard's group g, so the 64 x 45 sums are
-  // all-reduced and every rank derives the same initial guess from the same numbers.
-  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
-  if (collective) {
-    const int rc = allreduce_buffer(p, groups_dev, gsz);
-    if (rc) return rc;
-  }
-  SBA_HIP_TRY(hipMemcpyAsync(groups, groups_dev, gsz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
-  if (collective && p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
-    return fail(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's group moments");
-  return SBA_OK;
-}
-
-int sba_initial_guess_from_moments(const double* groups, int trials, double subset_fraction, unsigned long long seed,
-                                   double rot_euler[3], double tran[3], int* num_candidates) {
-  if (!groups || !rot_euler || !tran) return fail(SBA_ERR_INVALID_ARG, "null argument");
-  if (trials < 1 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
-    return fail(SBA_ERR_INVALID_ARG, "bad trials / subset_fraction");
-  const sba::epi::GuessResult r = sba::epi::initial_guess_from_groups(groups, trials, subset_fraction, seed,
-                                                                       g_host_threads.load());
-  if (num_candidates) *num_candidates = r.num_candidates;
-  if (r.picked < 0) return fail(SBA_ERR_NUMERIC, "no valid rotation candidate (all Euler angles >= 1.57)");
-  for (int i = 0; i < 3; ++i) { rot_euler[i] = r.euler[i]; tran[i] = r.tran[i]; }
-  return SBA_OK;
-}
-
-int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction, unsigned long long seed,
-                              double rot_euler[3], double tran[3], int* num_candidates) {
-  std::vector<double> groups(static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom);
-  const int rc = sba_problem_epipolar_moments(p, groups.data());
-  if (rc) return rc;
-  return sba_initial_guess_from_moments(groups.data(), trials, subset_fraction, seed, rot_euler, tran, num_candidates);
 }
 
 static int require_device(int device) {

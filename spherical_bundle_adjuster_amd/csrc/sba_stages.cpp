@@ -1,0 +1,228 @@
+// Entry points of the stages either side of the sweep (include/sba_hip.h): the d-only stage (reference
+// spherical_bundle_adjuster.cpp:1004-1063) and the 8-point initial guess (.cpp:47-181).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "sba_epipolar.hpp"
+#include "sba_lm.hpp"
+#include "sba_problem.hpp"
+#include "sba_rotation.hpp"
+
+using sba::shim::allreduce_buffer;
+using sba::shim::allreduce_pack;
+using sba::shim::fetch_pack_raw;
+
+extern "C" {
+
+// ---- callers / data formats either side of the path ----------------------------------------------
+int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
+                             double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary) {
+  if (!p || !rot || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  if (!p->has_d12 && p->n > 0) return sba::set_error(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
+  // Sharded problem: the six global reductions of every pass are all-reduced over the attached transport (the
+  // maximum travels as one slot per rank, so at most 16 shards), and every rank replays the same step logic.
+  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
+  if (collective && (p->shard_count < 1 || p->shard_count > 16 || p->shard_rank < 0 || p->shard_rank >= p->shard_count))
+    return sba::set_error(SBA_ERR_UNSUPPORTED, "d-only stage over a transport needs 1..16 shards (sba_problem_set_shard); have %d/%d",
+                p->shard_rank, p->shard_count);
+  SBA_TRY_HIP(hipSetDevice(p->device));
+  sba_lm_options o;
+  if (opt) o = *opt; else sba::lm_default_options(&o);
+  sba_lm_summary local;
+  sba_lm_summary* sum = summary ? summary : &local;
+  std::memset(sum, 0, sizeof(*sum));
+  const auto t_start = std::chrono::steady_clock::now();
+  const size_t n = p->n, elems = std::max<size_t>(p->plane_elems, 2);
+
+  // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, 8 results
+  sba::DeviceBuffer work_buf, partials_buf, out_buf;
+  SBA_TRY_HIP(work_buf.alloc(6 * elems * sizeof(double)));
+  double* work = work_buf.as<double>();
+  double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
+         *dg2 = work + 5 * elems;
+  // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
+  int& occ = p->depth_occ[p->store];
+  if (occ == 0) {
+    SBA_TRY_HIP(sba::depth_blocks_per_cu(p->store, &occ));
+    occ = std::max(1, occ);
+  }
+  int cap = 8;
+  if (const char* env = std::getenv("SBA_DEPTH_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) cap = v; }
+  const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256,
+                                                     static_cast<size_t>(p->num_cus) * std::max(1, std::min(occ, cap))));
+  SBA_TRY_HIP(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
+  SBA_TRY_HIP(out_buf.alloc(8 * sizeof(double)));
+  double *partials = partials_buf.as<double>(), *out_dev = out_buf.as<double>();
+
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+  sba::DepthParams prm;
+  double G[27];
+  sba::rotation_and_derivatives(rot, prm.R, G);
+  for (int i = 0; i < 3; ++i) prm.t[i] = tran[i];
+  prm.lambda = lambda; prm.c = c;
+  prm.min_diagonal = o.min_lm_diagonal; prm.max_diagonal = o.max_lm_diagonal;
+  prm.jacobi_scaling = o.jacobi_scaling; prm.pad_ = 0; prm.n = n;
+
+  double* cur1 = p->dplane[0];
+  double* cur2 = p->dplane[1];
+  double radius = o.initial_trust_region_radius, nu = 2.0;
+  bool reuse = false, first = true;
+  int invalid = 0, rc_final = SBA_OK;
+  double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto step = [&]() -> int {   // one device pass at the current depths
+    prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
+    if (collective) {
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                         p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
+      int rc = allreduce_pack(p);
+      if (rc) return rc;
+      double raw[SBA_PACK_SIZE];
+      rc = fetch_pack_raw(p, raw);
+      if (rc) return rc;
+      for (int k = 0; k < 5; ++k) out[k] = raw[k];
+      out[5] = 0.0;
+      for (int r = 0; r < p->shard_count; ++r) out[5] = std::max(out[5], raw[8 + r]);
+      sum->num_evaluations++;
+      first = false;
+      return SBA_OK;
+    }
+    if (p->publish) {
+      // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
+      const unsigned long long seq = ++p->seq;
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                         out_dev, p->pack_host_dev, seq, -1, p->stream));
+      const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), seq,
+                                            p->stream, "d-only pass");
+      if (rc) return rc;
+    } else {
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+                                         out_dev, nullptr, 0, -1, p->stream));
+      SBA_TRY_HIP(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+    }
+    std::memcpy(out, p->pack_host, sizeof(out));
+    sum->num_evaluations++;
+    first = false;
+    return SBA_OK;
+  };
+  auto finish = [&](int term, double cost, double gmax) {
+    sum->termination = term; sum->final_cost = cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius;
+    sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  };
+
+  for (int it = 1;; ++it) {
+    int rc = step();
+    if (rc) return rc;
+    const double cost = out[0], model = out[1], cand_cost = out[2], gmax = out[5];
+    if (it == 1) {
+      sum->initial_cost = cost;
+      if (!std::isfinite(cost)) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
+    }
+    // Ceres checks the gradient tolerance after every successful step (and at iteration 0): the gradient at the
+    // current point arrives with this pass.
+    if (!reuse && gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cost, gmax); break; }
+    if (it > o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cost, gmax); break; }
+    if (radius < o.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, cost, gmax); break; }
+    sum->num_iterations = it;
+    if (!(model > 0.0)) {
+      if (++invalid >= 5) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
+      radius /= nu; nu *= 2.0; reuse = true;
+      continue;
+    }
+    invalid = 0;
+    if (std::sqrt(out[3]) <= o.parameter_tolerance * (std::sqrt(out[4]) + o.parameter_tolerance)) {
+      finish(SBA_TERM_CONVERGENCE_PARAMETER, cost, gmax); break;
+    }
+    const double change = cost - cand_cost;
+    if (std::fabs(change) <= o.function_tolerance * cost) { finish(SBA_TERM_CONVERGENCE_FUNCTION, cost, gmax); break; }
+    const double quality = change / model;
+    if (quality > o.min_relative_decrease) {
+      std::swap(cur1, c1); std::swap(cur2, c2);     // the candidate planes become the current depths
+      sum->num_successful_steps++;
+      const double q = 2.0 * quality - 1.0;
+      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
+      nu = 2.0; reuse = false;
+    } else {
+      radius /= nu; nu *= 2.0; reuse = true;
+    }
+  }
+  // the problem's depth planes must end up holding the result
+  if (cur1 != p->dplane[0]) {
+    SBA_TRY_HIP(hipMemcpyAsync(p->dplane[0], cur1, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    SBA_TRY_HIP(hipMemcpyAsync(p->dplane[1], cur2, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+  }
+  if (d12_out && n > 0) {
+    sba::DeviceBuffer aos;
+    SBA_TRY_HIP(aos.alloc(2 * n * sizeof(double)));
+    SBA_TRY_HIP(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos.as<double>(), p->stream));
+    SBA_TRY_HIP(hipMemcpyAsync(d12_out, aos.ptr, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+  }
+  SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+  if (rc_final != SBA_OK) return sba::set_error(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
+  return SBA_OK;
+}
+
+// ---- 8-point initial guess (reference .cpp:47-181) -------------------------------------------------------
+int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
+  if (!p || !groups) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  SBA_TRY_HIP(hipSetDevice(p->device));
+  const size_t nquad = (p->n + 3) / 4;
+  const int grid = static_cast<int>(std::min<size_t>((nquad + 63) / 64, static_cast<size_t>(p->num_cus) * 4));
+  const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
+  // scratch (block partials + the groups) lives in the handle: allocating 23 MB per call cost more than the pass
+  const size_t need = (static_cast<size_t>(std::max(grid, 1)) + 1) * gsz;
+  if (p->epi_scratch_elems < need) {
+    if (p->epi_scratch) SBA_TRY_HIP(hipFree(p->epi_scratch));
+    p->epi_scratch = nullptr; p->epi_scratch_elems = 0;
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p->epi_scratch), need * sizeof(double)));
+    p->epi_scratch_elems = need;
+  }
+  double *groups_dev = p->epi_scratch, *partials = p->epi_scratch + gsz;
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+  SBA_TRY_HIP(sba::launch_epipolar_moments(p->store, pl, p->n, partials, grid, groups_dev, p->stream));
+  // Sharded problem: group g of the whole problem is the union of every shard's group g, so the 64 x 45 sums are
+  // all-reduced and every rank derives the same initial guess from the same numbers.
+  const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
+  if (collective) {
+    const int rc = allreduce_buffer(p, groups_dev, gsz);
+    if (rc) return rc;
+  }
+  SBA_TRY_HIP(hipMemcpyAsync(groups, groups_dev, gsz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+  if (collective && p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
+    return sba::set_error(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's group moments");
+  return SBA_OK;
+}
+
+int sba_initial_guess_from_moments(const double* groups, int trials, double subset_fraction, unsigned long long seed,
+                                   double rot_euler[3], double tran[3], int* num_candidates) {
+  if (!groups || !rot_euler || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  if (trials < 1 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "bad trials / subset_fraction");
+  const sba::epi::GuessResult r = sba::epi::initial_guess_from_groups(groups, trials, subset_fraction, seed,
+                                                                       sba::host_threads());
+  if (num_candidates) *num_candidates = r.num_candidates;
+  if (r.picked < 0) return sba::set_error(SBA_ERR_NUMERIC, "no valid rotation candidate (all Euler angles >= 1.57)");
+  for (int i = 0; i < 3; ++i) { rot_euler[i] = r.euler[i]; tran[i] = r.tran[i]; }
+  return SBA_OK;
+}
+
+int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction, unsigned long long seed,
+                              double rot_euler[3], double tran[3], int* num_candidates) {
+  std::vector<double> groups(static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom);
+  const int rc = sba_problem_epipolar_moments(p, groups.data());
+  if (rc) return rc;
+  return sba_initial_guess_from_moments(groups.data(), trials, subset_fraction, seed, rot_euler, tran, num_candidates);
+}
+
+}  // extern "C"
