@@ -1,0 +1,246 @@
+// Batched kernels (BASELINE config C5): many independent two-view problems ("pairs") per launch -- the batched sweep,
+// the per-pair preparation of the sweep state, and the fold + moment conversion + publication of all packs.
+// Device core shared with the single-problem sweep: sba_sweep_core.hpp.
+#include "sba_sweep_core.hpp"
+
+namespace sba {
+namespace {
+
+// ---- batched sweep: many independent two-view problems ("pairs") in ONE launch (BASELINE config C5) ------------
+// Block group g = blockIdx.x / bpp works on pair g with that pair's own R|t (params[g], wave-uniform address ->
+// scalar loads), blocks j = blockIdx.x % bpp of the group grid-stride over the pair's vectors.  Rows of block
+// partials are folded per pair by batch_finalize_kernel.  A pair with n == 0 (e.g. already converged) costs its
+// blocks only the row store.
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const SweepParams* __restrict__ params,
+                                                            const PairDesc* __restrict__ desc, int bpp,
+                                                            double* __restrict__ partials) {
+  constexpr int NACC = AccMap<MODE, KIND>::N;
+  constexpr int PPT = Lanes<ST>::PPT;
+  __shared__ double lds[(kBlock / 64) * 24];
+  double* wave_out = lds;
+  const int tid = threadIdx.x;
+  const unsigned pair = blockIdx.x / static_cast<unsigned>(bpp), j = blockIdx.x % static_cast<unsigned>(bpp);
+  const SweepParams* __restrict__ P = params + pair;
+  const size_t n = P->n, first = desc[pair].first_vec;
+  const size_t stride = static_cast<size_t>(bpp) * kBlock;
+
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  const size_t nfull = n / PPT;
+  size_t p = static_cast<size_t>(j) * kBlock + tid;
+  VecRegs<ST, DEPTH> cur, nxt;
+  if (p < nfull) cur.load(pl, first + p);
+  while (p < nfull) {
+    const size_t pn = p + stride;
+    if (pn < nfull) nxt.load(pl, first + pn);
+    consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, P, p, n, acc);
+    cur = nxt;
+    p = pn;
+  }
+  if (nfull * PPT != n && j == static_cast<unsigned>(bpp) - 1 && tid == kBlock - 1) {
+    cur.load(pl, first + nfull);
+    consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, P, nfull, n, acc);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const double s = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) wave_out[wave * 24 + AccMap<MODE, KIND>::slot(k)] = s;
+  }
+  if (NACC < 24 && tid < 24) {
+    bool used = false;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) used |= (AccMap<MODE, KIND>::slot(k) == tid);
+    if (!used) {
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64; ++wv) wave_out[wv * 24 + tid] = 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid < kRow) {
+    double s = 0.0;
+    if (tid < 24) {
+      s = wave_out[tid];
+#pragma unroll
+      for (int wv = 1; wv < kBlock / 64; ++wv) s += wave_out[wv * 24 + tid];
+    }
+    partials[static_cast<size_t>(blockIdx.x) * kRow + tid] = s;
+  }
+}
+
+// ONE block folds every pair's bpp rows (fixed order) into packs[pair][24], on the device and -- when packs_host is
+// given -- in mapped pinned host memory, followed by a system-scope release and the sequence number in
+// packs_host[24 * num_pairs]: the host polls that word instead of queueing a D2H copy and synchronising the stream.
+__global__ __launch_bounds__(1024) void batch_finalize_kernel(const double* __restrict__ partials, int bpp,
+                                                              int num_pairs, double* __restrict__ packs,
+                                                              double* __restrict__ packs_host,
+                                                              unsigned long long seq) {
+  const int items = num_pairs * 24;
+  for (int it = threadIdx.x; it < items; it += 1024) {
+    const int pair = it / 24, slot = it - pair * 24;
+    const double* rows = partials + static_cast<size_t>(pair) * bpp * kRow + slot;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < bpp; b += 4) {
+      s0 += rows[static_cast<size_t>(b) * kRow];
+      s1 += rows[static_cast<size_t>(b + 1) * kRow];
+      s2 += rows[static_cast<size_t>(b + 2) * kRow];
+      s3 += rows[static_cast<size_t>(b + 3) * kRow];
+    }
+    for (; b < bpp; ++b) s0 += rows[static_cast<size_t>(b) * kRow];
+    const double tot = (s0 + s1) + (s2 + s3);
+    packs[it] = tot;
+    if (packs_host) packs_host[it] = tot;
+  }
+  if (!packs_host) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // every thread: its host stores before the barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + items), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- batched step with the per-pair host work moved to the device ----------------------------------------------
+// One thread per pair: SweepParams (rotation, its derivatives, the Huber constants) from the pair's (rot, tran, depths)
+// in `state` (mapped host memory: 80 B per pair instead of the 344-byte SweepParams crossing PCIe), and for the factored
+// kernel the frame (B, J) that batch_convert_finalize_kernel applies to the pair's moments.
+__global__ __launch_bounds__(64) void batch_prepare_kernel(const BatchState* __restrict__ state, int num_pairs,
+                                                           int depth_mode, double huber_delta, int with_frames,
+                                                           SweepParams* __restrict__ params,
+                                                           double* __restrict__ frames) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= num_pairs) return;
+  const BatchState st = state[g];
+  SweepParams prm;
+  fill_sweep_params(st.n, depth_mode, st.rot, st.tran, st.d1, st.d2, huber_delta, &prm);
+  params[g] = prm;
+  if (with_frames) {
+    double B[9], J[9];
+    factored_frame(st.rot, B, J);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { frames[18 * g + i] = B[i]; frames[18 * g + 9 + i] = J[i]; }
+  }
+}
+
+// Fold (as batch_finalize_kernel), then one thread per pair maps the moment pack to the SBA_PACK_* layout with the
+// pair's own frame, and everything is published to the host.  convert: 1 = rot free, 2 = rot + tran free.
+__global__ __launch_bounds__(1024) void batch_convert_finalize_kernel(const double* __restrict__ partials, int bpp,
+                                                                      int num_pairs, const double* __restrict__ frames,
+                                                                      int convert, double* __restrict__ packs,
+                                                                      double* __restrict__ packs_host,
+                                                                      unsigned long long seq) {
+  const int items = num_pairs * 24;
+  for (int it = threadIdx.x; it < items; it += 1024) {
+    const int pair = it / 24, slot = it - pair * 24;
+    const double* rows = partials + static_cast<size_t>(pair) * bpp * kRow + slot;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < bpp; b += 4) {
+      s0 += rows[static_cast<size_t>(b) * kRow];
+      s1 += rows[static_cast<size_t>(b + 1) * kRow];
+      s2 += rows[static_cast<size_t>(b + 2) * kRow];
+      s3 += rows[static_cast<size_t>(b + 3) * kRow];
+    }
+    for (; b < bpp; ++b) s0 += rows[static_cast<size_t>(b) * kRow];
+    packs[it] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();                                         // the raw packs of this block are visible to all its threads
+  for (int pair = threadIdx.x; pair < num_pairs; pair += 1024) {
+    double raw[24], out[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) raw[k] = packs[pair * 24 + k];
+    moments_to_normal_pack(true, convert == 2, frames + 18 * pair, frames + 18 * pair + 9, raw, out);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      packs[pair * 24 + k] = out[k];
+      if (packs_host) packs_host[pair * 24 + k] = out[k];
+    }
+  }
+  if (!packs_host) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + items), seq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ---- batch kernel table (same template axes as the single-problem sweep) ---------------------------------------
+typedef void (*BatchFn)(Planes, const SweepParams*, const PairDesc*, int, double*);
+template <int MODE, int DEPTH, typename ST, int KIND>
+BatchFn bpick_loss(bool loss) {
+  return loss ? batch_sweep_kernel<MODE, DEPTH, ST, KIND, true> : batch_sweep_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+BatchFn bpick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? bpick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss)
+                               : bpick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
+template <int MODE, int DEPTH>
+BatchFn bpick_store(int store, int kind, bool loss) {
+  return store == 0 ? bpick_kind<MODE, DEPTH, double>(kind, loss) : bpick_kind<MODE, DEPTH, float>(kind, loss);
+}
+BatchFn bpick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return bpick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return bpick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return bpick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return bpick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return bpick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return bpick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
+}
+
+}  // namespace
+
+hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks) {
+  BatchFn fn = bpick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(fn), kBlock, 0);
+}
+
+hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
+                              const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
+                              double* partials, double* packs, double* packs_host, unsigned long long seq,
+                              hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchFn fn = bpick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs) * bpp), dim3(kBlock), 0, stream, pl, params, desc,
+                     bpp, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
+                     packs_host, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_step(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
+                             const BatchState* state, SweepParams* params, double* frames, const PairDesc* desc,
+                             int num_pairs, int bpp, double* partials, double* packs, double* packs_host,
+                             unsigned long long seq, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchFn fn = bpick(mode, depth, store, kind, huber_delta > 0.0);
+  if (!fn) return hipErrorInvalidValue;
+  const int convert = (kind == KIND_FACTORED && mode != MODE_TRAN) ? (mode == MODE_RT ? 2 : 1) : 0;
+  hipLaunchKernelGGL(batch_prepare_kernel, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, state, num_pairs, depth,
+                     huber_delta, convert != 0 ? 1 : 0, params, frames);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs) * bpp), dim3(kBlock), 0, stream, pl, params, desc, bpp,
+                     partials);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (convert != 0)
+    hipLaunchKernelGGL(batch_convert_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, frames,
+                       convert, packs, packs_host, seq);
+  else
+    hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
+                       packs_host, seq);
+  return hipGetLastError();
+}
+
+}  // namespace sba

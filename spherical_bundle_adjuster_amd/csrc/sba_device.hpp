@@ -1,5 +1,5 @@
 // Internal interface between the C-ABI shim (sba_shim.cpp) and the HIP kernels
-// (sba_kernels.hip).  Nothing here is exported.
+// (sba_kernels.hip, sba_batch_kernels.hip, sba_side.hip, sba_depth.hip, sba_epipolar.hip).  Nothing here is exported.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
