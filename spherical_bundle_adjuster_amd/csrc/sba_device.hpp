@@ -112,6 +112,7 @@ struct BatchState {
   unsigned long long n;
   unsigned long long pad_;
 };
+static_assert(sizeof(BatchState) == 80, "BatchState is copied word by word");
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
