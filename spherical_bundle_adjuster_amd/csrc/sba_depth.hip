@@ -7,7 +7,7 @@
 // iteration splits into N independent 2x2 solves -- but radius, accept/reject, Jacobi scaling and the convergence
 // tests are global.  depth_step_kernel therefore does, for every match in one pass: residuals + 5x2 Jacobian at the
 // current depths, the scaled damped 2x2 solve, the projected candidate, the candidate's cost, and contributes to
-// the six global reductions the host needs for Ceres' step logic (sba_shim.cpp: sba_problem_solve_depths).
+// the six global reductions the host needs for Ceres' step logic (sba_stages.cpp: sba_problem_solve_depths).
 // Two matches per lane, 16-byte accesses (1 KiB per wave instruction) -- HBM-bound: 8-12 loads + 4-8 stores of
 // 8 B per match and iteration (96-128 B).
 #include "sba_device.hpp"

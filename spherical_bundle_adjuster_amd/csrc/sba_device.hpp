@@ -1,4 +1,4 @@
-// Internal interface between the C-ABI shim (sba_shim.cpp) and the HIP kernels
+// Internal interface between the C-ABI translation units (sba_shim / sba_transport / sba_stages / sba_batch .cpp) and the HIP kernels
 // (sba_kernels.hip, sba_batch_kernels.hip, sba_side.hip, sba_depth.hip, sba_epipolar.hip).  Nothing here is exported.
 #pragma once
 #include <hip/hip_runtime.h>
