@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SBA_ABI_VERSION 1
+#define SBA_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------ */
 enum {
@@ -136,6 +136,14 @@ typedef struct sba_lm_options {
   double huber_delta;                 /* 1.0 (.cpp:887,:943,:1000); <= 0 disables the loss */
   int tran_param;                     /* SBA_TRAN_FREE (reference) or SBA_TRAN_SPHERE       */
   int verbose;                        /* 1 = per-iteration line on stdout (.cpp:337)        */
+  /* Projected line search of a bounds-constrained problem -- only the d-only stage has bounds
+   * (.cpp:1060-1061).  Ceres runs it on every trust-region step when the count below is > 0; the
+   * reference leaves all five at Ceres' defaults.  ARMIJO, CUBIC interpolation.  0 = off.        */
+  int max_num_line_search_step_size_iterations;    /* 20                                     */
+  double line_search_sufficient_function_decrease; /* 1e-4                                   */
+  double max_line_search_step_contraction;         /* 1e-3                                   */
+  double min_line_search_step_contraction;         /* 0.6                                    */
+  double min_line_search_step_size;                /* 1e-9                                   */
 } sba_lm_options;
 
 enum {
@@ -158,6 +166,7 @@ typedef struct sba_lm_summary {
   double final_radius;
   double seconds_total;       /* wall clock of the whole solve                             */
   double seconds_eval;        /* of which: waiting for the device sweeps                   */
+  int num_line_search_steps;  /* d-only stage: step-size contractions of the projected line search */
 } sba_lm_summary;
 
 typedef struct sba_problem sba_problem; /* opaque: one shard of correspondences on one GPU  */
@@ -231,6 +240,14 @@ int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const doubl
                            int repeat, double pack[SBA_PACK_SIZE], double* mean_step_ms,
                            double* mean_sweep_ms);
 
+/* The sweep kernel launched `repeat` times back to back with a HIP event recorded between every two launches on the
+ * problem's stream: launch_ms[i] = device time from the event before launch i to the event after it (the kernel plus
+ * one event boundary).  Shows the spread of the dominant kernel -- first launches after idle run at ramping clocks --
+ * that the mean of sba_problem_eval_timed hides.  repeat <= 4096.                                            */
+int sba_problem_eval_launch_times(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                                  const double tran[3], double d1, double d2, double huber_delta,
+                                  int repeat, float* launch_ms);
+
 /* `steps` complete, host-synchronous sweeps in a row -- each one exactly what an LM iteration costs (launch,
  * reduction, all-reduce if installed, result on the host before the next launch) -- without a language binding
  * between them.  Returns the last pack and the wall-clock seconds of the loop.                               */
@@ -252,9 +269,12 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
  * 3-vector and lambda*exp(-c*d1), lambda*exp(-c*d2); no loss; lower bound 0; the reference uses lambda = c = 1).
  * Needs per-match depths uploaded (they are the initial values, init_d) and updates them on the device, so a
  * following SBA_DEPTH_PER_MATCH sweep sees the refined depths.  d12_out (double[2n], may be NULL) receives
- * them in init_d layout.  opt NULL = defaults (huber_delta / tran_param are ignored).  With a transport
- * attached (sharded problem) the six global reductions of every pass are all-reduced, all ranks take the
- * same steps, and every rank receives its own shard's depths (at most 16 shards, see sba_problem_set_shard). */
+ * them in init_d layout.  opt NULL = defaults (huber_delta / tran_param are ignored).  Every trust-region step
+ * goes through Ceres' projected Armijo line search first (the problem is bounds-constrained and the reference
+ * leaves max_num_line_search_step_size_iterations at 20): the first trial, step size 1, is evaluated by the same
+ * device pass that computes the step; each contraction costs one more pass.  With a transport attached (sharded
+ * problem) the nine global reductions of every pass are all-reduced, all ranks take the same steps, and every
+ * rank receives its own shard's depths (at most 8 shards, see sba_problem_set_shard).                       */
 int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
                              double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary);
 
@@ -280,8 +300,9 @@ int sba_problem_peer_disable(sba_problem* p);
 /* Option B: user hook (e.g. torch.distributed.all_reduce on a tensor aliasing device_buf).  */
 int sba_problem_set_allreduce(sba_problem* p, sba_allreduce_fn fn, void* user);
 /* Which shard of the correspondences this problem holds.  sba_problem_comm_init_rank and sba_problem_peer_export set
- * it themselves; with the user hook call it explicitly before sba_problem_solve_depths, whose gradient max-norm
- * travels through the SUM all-reduce as one pack slot per shard (hence at most 16 shards).                         */
+ * it themselves; with the user hook call it explicitly before sba_problem_solve_depths, whose two max-norms
+ * (projected gradient, step) travel through the SUM all-reduce as one pack slot per shard each (hence at most 8
+ * shards).                                                                                                         */
 int sba_problem_set_shard(sba_problem* p, int rank, int nranks);
 /* Device address of the 24-double result pack the hook / RCCL operates on (a sum over
  * correspondences in either kernel's layout, so summing it across shards is exact).            */

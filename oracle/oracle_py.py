@@ -32,17 +32,23 @@ class LmOptions(C.Structure):   # same field order as sba_lm_options
                 ("jacobi_scaling", C.c_int),
                 ("huber_delta", C.c_double),
                 ("tran_param", C.c_int),
-                ("verbose", C.c_int)]
+                ("verbose", C.c_int),
+                ("max_num_line_search_step_size_iterations", C.c_int),
+                ("line_search_sufficient_function_decrease", C.c_double),
+                ("max_line_search_step_contraction", C.c_double),
+                ("min_line_search_step_contraction", C.c_double),
+                ("min_line_search_step_size", C.c_double)]
 
 
 class LmSummary(C.Structure):
     _fields_ = [("termination", C.c_int), ("num_iterations", C.c_int), ("num_successful_steps", C.c_int),
                 ("num_evaluations", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
-                ("final_gradient_max_norm", C.c_double), ("final_radius", C.c_double)]
+                ("final_gradient_max_norm", C.c_double), ("final_radius", C.c_double),
+                ("num_line_search_steps", C.c_int)]
 
 
 def default_options(**kw) -> LmOptions:
-    o = LmOptions(50, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 1, 1.0, 0, 0)
+    o = LmOptions(50, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 1, 1.0, 0, 0, 20, 1e-4, 1e-3, 0.6, 1e-9)
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)
@@ -200,3 +206,42 @@ def crop_rotated_image(im: np.ndarray, pitch_deg: float) -> np.ndarray:
     out = np.zeros((im.shape[0] // 4, im.shape[1], 3), dtype=np.uint8)
     lib().orc_crop_rotated_image(_p(im), C.c_int(im.shape[0]), C.c_int(im.shape[1]), C.c_float(pitch_deg), _p(out))
     return out
+
+
+def interpolating_polynomial(samples):
+    """samples: rows (x, value, gradient) -- every value and gradient valid.  Coefficients, highest degree first."""
+    a = _f64(samples).reshape(-1, 3)
+    out = np.zeros(2 * a.shape[0])
+    lib().orc_ls_interpolating_polynomial(_p(a), C.c_int(a.shape[0]), _p(out))
+    return out
+
+
+def minimize_polynomial(poly, x_min, x_max):
+    poly = _f64(poly)
+    out = np.zeros(2)
+    lib().orc_ls_minimize_polynomial(_p(poly), C.c_int(poly.size), C.c_double(x_min), C.c_double(x_max), _p(out))
+    return float(out[0]), float(out[1])
+
+
+PHI_CB = C.CFUNCTYPE(C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def armijo(phi, cost0, slope0, direction_max_norm=1.0, options: LmOptions | None = None):
+    """Ceres' Armijo search (first trial 1.0) on phi(a) -> (value, slope).  Returns (success, step size, contractions)."""
+    o = options if options is not None else default_options()
+
+    def _cb(a, v, g, _u):
+        try:
+            v[0], g[0] = map(float, phi(a))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -1
+    out = np.zeros(3)
+    lib().orc_ls_armijo.restype = C.c_int
+    rc = lib().orc_ls_armijo(C.byref(o), C.c_double(cost0), C.c_double(slope0), C.c_double(direction_max_norm),
+                             PHI_CB(_cb), None, _p(out))
+    if rc != 0:
+        raise RuntimeError("phi callback failed")
+    return bool(out[0]), float(out[1]), int(out[2])

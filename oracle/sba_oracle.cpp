@@ -23,6 +23,8 @@
 #include <cstring>
 #include <vector>
 
+#include "ceres_line_search.hpp"
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -351,8 +353,14 @@ struct LmOptions {   // mirrors the fields of sba_lm_options that the tests set 
   double huber_delta;
   int tran_param;
   int verbose;
+  // projected line search of bounds-constrained problems (d-only stage), Ceres Solver::Options names
+  int max_num_line_search_step_size_iterations;      // 20; 0 = no line search
+  double line_search_sufficient_function_decrease;   // 1e-4
+  double max_line_search_step_contraction;           // 1e-3
+  double min_line_search_step_contraction;           // 0.6
+  double min_line_search_step_size;                  // 1e-9
 };
-struct LmSummary { int termination, num_iterations, num_successful_steps, num_evaluations; double initial_cost, final_cost, final_gradient_max_norm, final_radius; };
+struct LmSummary { int termination, num_iterations, num_successful_steps, num_evaluations; double initial_cost, final_cost, final_gradient_max_norm, final_radius; int num_line_search_steps; };
 
 void perp_basis(const double t[3], double b0[3], double b1[3]) {
   const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
@@ -475,12 +483,13 @@ int orc_lm_solve(int mode, int per_match_depth, const double* x1, const double* 
   bool reuse_diag = false;
   int invalid = 0;
   auto done = [&](int term) { sum->termination = term; sum->final_cost = cur.cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius; return 0; };
-  if (gmax <= o.gradient_tolerance) return done(2);
 
-  for (int it = 1;; ++it) {
-    if (it > o.max_num_iterations) return done(4);
+  for (int it = 0;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue: iteration limit, gradient tolerance, minimum radius
+    if (it >= o.max_num_iterations) return done(4);
+    if (gmax <= o.gradient_tolerance) return done(2);
     if (radius < o.min_trust_region_radius) return done(5);
-    sum->num_iterations = it;
+    sum->num_iterations = ++it;
     std::vector<double> Hs(static_cast<size_t>(m) * m), gs(static_cast<size_t>(m)), A, rhs(static_cast<size_t>(m)), y(static_cast<size_t>(m));
     for (int i = 0; i < m; ++i) { gs[i] = scale[i] * g[i]; for (int j = 0; j < m; ++j) Hs[i * m + j] = scale[i] * H[i * m + j] * scale[j]; }
     if (!reuse_diag) for (int i = 0; i < m; ++i) diag[i] = std::min(std::max(Hs[i * m + i], o.min_lm_diagonal), o.max_lm_diagonal);
@@ -520,7 +529,6 @@ int orc_lm_solve(int mode, int per_match_depth, const double* x1, const double* 
       const double q = 2.0 * quality - 1.0;
       radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
       nu = 2.0; reuse_diag = false;
-      if (gmax <= o.gradient_tolerance) return done(2);
     } else {
       radius /= nu; nu *= 2; reuse_diag = true;
     }
@@ -532,8 +540,13 @@ int orc_lm_solve(int mode, int per_match_depth, const double* x1, const double* 
 // (AutoDiffCostFunction<d_only, 5, 2>, .cpp:1044), no loss (NULL, .cpp:1059), lower bound 0 on both
 // (.cpp:1060-1061), lambda = c = 1 (.cpp:1057-1058).  The Hessian is block diagonal, but it is ONE trust-region
 // problem: a single radius, a single accept/reject on the total cost, global convergence tests, Jacobi
-// scaling per parameter, and Plus() projects the candidate onto the bounds (Ceres' box-constraint handling;
-// max_num_line_search_step_size_iterations defaults to 0, so no projected line search).
+// scaling per parameter, and Plus() projects the candidate onto the bounds (ParameterBlock::Plus).
+// Because the problem is bounds-constrained and Solver::Options::max_num_line_search_step_size_iterations is
+// left at its default of 20 (.cpp:334-338 touch only four other fields), every trust-region step first goes
+// through Ceres' projected Armijo line search (ceres_line_search.hpp) before the candidate is evaluated.
+// (ITERATIVE_SCHUR, .cpp:335: every parameter block here is its own independent set, so all of them are
+// eliminated, the Schur complement is empty and the "iterative" solver is an exact block back-substitution --
+// the 2x2 solves below.)
 }  // extern "C"
 namespace {
 template <typename T>
@@ -553,8 +566,9 @@ int orc_depth_solve(const double* x1, const double* x2, size_t n, const double* 
                     LmSummary* sum) {
   const LmOptions& o = *opt;
   std::memset(sum, 0, sizeof(*sum));
-  std::vector<double> scale(2 * n), diag(2 * n), cand(2 * n), H(3 * n), g(2 * n);
-  auto evaluate = [&](const double* d, bool with_jac, double* gmax) {
+  std::vector<double> scale(2 * n), diag(2 * n), cand(2 * n), delta(2 * n), H(3 * n), g(2 * n), gtmp(2 * n);
+  // cost at d; with_jac: also the block Hessians H, the gradient into gout and the projected-gradient max norm
+  auto evaluate = [&](const double* d, bool with_jac, double* gout, double* Hout, double* gmax) {
     long double cost = 0;
     double gm = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -567,7 +581,8 @@ int orc_depth_solve(const double* x1, const double* x2, size_t n, const double* 
           h11 += res[k].d[0] * res[k].d[0]; h12 += res[k].d[0] * res[k].d[1]; h22 += res[k].d[1] * res[k].d[1];
           g1 += res[k].d[0] * res[k].v; g2 += res[k].d[1] * res[k].v; s += res[k].v * res[k].v;
         }
-        H[3 * i] = h11; H[3 * i + 1] = h12; H[3 * i + 2] = h22; g[2 * i] = g1; g[2 * i + 1] = g2;
+        if (Hout) { Hout[3 * i] = h11; Hout[3 * i + 1] = h12; Hout[3 * i + 2] = h22; }
+        gout[2 * i] = g1; gout[2 * i + 1] = g2;
         cost += 0.5L * s;
         // projected gradient norm for the bounded problem: |x - P(x - g)|_inf
         gm = std::max(gm, std::fabs(d[2 * i] - std::max(d[2 * i] - g1, 0.0)));
@@ -584,7 +599,7 @@ int orc_depth_solve(const double* x1, const double* x2, size_t n, const double* 
     return static_cast<double>(cost);
   };
   double gmax = 0;
-  double cost = evaluate(d12, true, &gmax);
+  double cost = evaluate(d12, true, g.data(), H.data(), &gmax);
   sum->initial_cost = cost;
   for (size_t k = 0; k < 2 * n; ++k) {
     const double hkk = H[3 * (k / 2) + (k % 2 ? 2 : 0)];
@@ -594,12 +609,14 @@ int orc_depth_solve(const double* x1, const double* x2, size_t n, const double* 
   bool reuse = false;
   int invalid = 0;
   auto done = [&](int term) { sum->termination = term; sum->final_cost = cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius; return 0; };
-  if (gmax <= o.gradient_tolerance) return done(2);
-  for (int it = 1;; ++it) {
-    if (it > o.max_num_iterations) return done(4);
+  for (int it = 0;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue: iteration limit, gradient tolerance, minimum radius
+    if (it >= o.max_num_iterations) return done(4);
+    if (gmax <= o.gradient_tolerance) return done(2);
     if (radius < o.min_trust_region_radius) return done(5);
-    sum->num_iterations = it;
-    long double model = 0, step2 = 0, x2n = 0;
+    sum->num_iterations = ++it;
+    long double model = 0, x2n = 0, gdelta = 0;
+    double dmax = 0;
     for (size_t i = 0; i < n; ++i) {
       const double s1 = scale[2 * i], s2 = scale[2 * i + 1];
       const double h11 = s1 * H[3 * i] * s1, h12 = s1 * H[3 * i + 1] * s2, h22 = s2 * H[3 * i + 2] * s2;
@@ -612,33 +629,85 @@ int orc_depth_solve(const double* x1, const double* x2, size_t n, const double* 
       const double det = a11 * a22 - a12 * a12;
       const double y1 = (-g1 * a22 + g2 * a12) / det, y2 = (-g2 * a11 + g1 * a12) / det;
       model += -(g1 * y1 + g2 * y2) - 0.5 * (h11 * y1 * y1 + 2 * h12 * y1 * y2 + h22 * y2 * y2);
-      cand[2 * i] = std::max(d12[2 * i] + s1 * y1, 0.0);           // Plus + projection onto d >= 0
-      cand[2 * i + 1] = std::max(d12[2 * i + 1] + s2 * y2, 0.0);
+      delta[2 * i] = s1 * y1; delta[2 * i + 1] = s2 * y2;      // delta = step .* jacobian_scaling
       for (int k = 0; k < 2; ++k) {
-        const double dd = cand[2 * i + k] - d12[2 * i + k];
-        step2 += static_cast<long double>(dd) * dd;
+        gdelta += static_cast<long double>(g[2 * i + k]) * delta[2 * i + k];
+        dmax = std::max(dmax, std::fabs(delta[2 * i + k]));
         x2n += static_cast<long double>(d12[2 * i + k]) * d12[2 * i + k];
       }
     }
     if (!(model > 0)) { if (++invalid >= 5) { done(6); return -6; } radius /= nu; nu *= 2; reuse = true; continue; }
     invalid = 0;
-    const double cand_cost = evaluate(cand.data(), false, nullptr);
+    // x_plus(a) = Plus(x, a * delta): add, then project onto d >= 0
+    auto plus = [&](double a, double* out) { for (size_t k = 0; k < 2 * n; ++k) out[k] = std::max(d12[k] + a * delta[k], 0.0); };
+    if (o.max_num_line_search_step_size_iterations > 0) {     // TrustRegionMinimizer::DoLineSearch
+      orc_ls::Options lo;
+      lo.max_num_iterations = o.max_num_line_search_step_size_iterations;
+      lo.sufficient_decrease = o.line_search_sufficient_function_decrease;
+      lo.max_step_contraction = o.max_line_search_step_contraction;
+      lo.min_step_contraction = o.min_line_search_step_contraction;
+      lo.min_step_size = o.min_line_search_step_size;
+      const orc_ls::Summary ls = orc_ls::armijo_search(lo, cost, static_cast<double>(gdelta), dmax,
+          [&](double a, double* value, double* dir_gradient) {
+            plus(a, cand.data());
+            *value = evaluate(cand.data(), true, gtmp.data(), nullptr, nullptr);
+            long double s = 0;
+            for (size_t k = 0; k < 2 * n; ++k) s += static_cast<long double>(gtmp[k]) * delta[k];
+            *dir_gradient = static_cast<double>(s);
+            return true;
+          });
+      sum->num_line_search_steps += ls.num_iterations;
+      if (ls.success) for (size_t k = 0; k < 2 * n; ++k) delta[k] *= ls.step_size;
+    }
+    plus(1.0, cand.data());
+    long double step2 = 0;
+    for (size_t k = 0; k < 2 * n; ++k) { const double dd = cand[k] - d12[k]; step2 += static_cast<long double>(dd) * dd; }
+    const double cand_cost = evaluate(cand.data(), false, nullptr, nullptr, nullptr);
     if (std::sqrt(static_cast<double>(step2)) <= o.parameter_tolerance * (std::sqrt(static_cast<double>(x2n)) + o.parameter_tolerance)) return done(3);
     const double change = cost - cand_cost;
     if (std::fabs(change) <= o.function_tolerance * cost) return done(1);
     const double quality = change / static_cast<double>(model);
     if (quality > o.min_relative_decrease) {
       std::memcpy(d12, cand.data(), sizeof(double) * 2 * n);
-      cost = evaluate(d12, true, &gmax);
+      cost = evaluate(d12, true, g.data(), H.data(), &gmax);
       sum->num_successful_steps++;
       const double q = 2.0 * quality - 1.0;
       radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
       nu = 2.0; reuse = false;
-      if (gmax <= o.gradient_tolerance) return done(2);
     } else {
       radius /= nu; nu *= 2; reuse = true;
     }
   }
+}
+
+// Line-search pieces on their own (tests pin them against numpy.linalg.solve / numpy.roots).
+void orc_ls_interpolating_polynomial(const double* samples /* k x (x, value, gradient) */, int k, double* coeffs) {
+  std::vector<orc_ls::Sample> v(static_cast<size_t>(k));
+  for (int i = 0; i < k; ++i) {
+    v[i].x = samples[3 * i]; v[i].value = samples[3 * i + 1]; v[i].gradient = samples[3 * i + 2];
+    v[i].value_is_valid = v[i].gradient_is_valid = true;
+  }
+  const std::vector<double> p = orc_ls::find_interpolating_polynomial(v);
+  std::memcpy(coeffs, p.data(), sizeof(double) * p.size());
+}
+// ArmijoLineSearch::DoSearch on a caller-supplied phi(a) -> (value, slope); out3 = {success, step size, contractions}.
+typedef int (*orc_phi_cb)(double step_size, double* value, double* slope, void* user);
+int orc_ls_armijo(const LmOptions* o, double cost0, double slope0, double direction_max_norm, orc_phi_cb phi,
+                  void* user, double* out3) {
+  orc_ls::Options lo;
+  lo.max_num_iterations = o->max_num_line_search_step_size_iterations;
+  lo.sufficient_decrease = o->line_search_sufficient_function_decrease;
+  lo.max_step_contraction = o->max_line_search_step_contraction;
+  lo.min_step_contraction = o->min_line_search_step_contraction;
+  lo.min_step_size = o->min_line_search_step_size;
+  int cb_rc = 0;
+  const orc_ls::Summary r = orc_ls::armijo_search(lo, cost0, slope0, direction_max_norm,
+      [&](double a, double* v, double* g) { if (phi(a, v, g, user) != 0) { cb_rc = -1; return false; } return true; });
+  out3[0] = r.success ? 1.0 : 0.0; out3[1] = r.step_size; out3[2] = r.num_iterations;
+  return cb_rc;
+}
+void orc_ls_minimize_polynomial(const double* poly, int size, double x_min, double x_max, double* out2) {
+  orc_ls::minimize_polynomial(std::vector<double>(poly, poly + size), x_min, x_max, &out2[0], &out2[1]);
 }
 
 // ---- pixel -> unit sphere, spherical_bundle_adjuster.cpp:271-298 -------------------------------------

@@ -3,6 +3,6 @@
 
 Importing the package does not load the HIP library; the first API call does and fails loudly
 (``LibraryNotBuilt``) if ``libsba_hip.so`` has not been built."""
-from ._cabi import LibraryNotBuilt, SbaError, load_library  # noqa: F401
+from ._cabi import ABI_VERSION, LibraryNotBuilt, SbaError, load_library  # noqa: F401
 
-__all__ = ["LibraryNotBuilt", "SbaError", "load_library"]
+__all__ = ["ABI_VERSION", "LibraryNotBuilt", "SbaError", "load_library"]

@@ -23,6 +23,7 @@ STORE_F64, STORE_F32 = 0, 1
 TRAN_FREE, TRAN_SPHERE = 0, 1
 KERNEL_FACTORED, KERNEL_EXPLICIT = 0, 1
 PACK_SIZE = 24
+ABI_VERSION = 2          # SBA_ABI_VERSION of include/sba_hip.h
 COMM_ID_BYTES = 128
 PEER_HANDLE_BYTES = 64
 TERMINATION = {1: "CONVERGENCE_FUNCTION", 2: "CONVERGENCE_GRADIENT", 3: "CONVERGENCE_PARAMETER",
@@ -59,7 +60,12 @@ class LmOptions(C.Structure):
                 ("jacobi_scaling", C.c_int),
                 ("huber_delta", C.c_double),
                 ("tran_param", C.c_int),
-                ("verbose", C.c_int)]
+                ("verbose", C.c_int),
+                ("max_num_line_search_step_size_iterations", C.c_int),
+                ("line_search_sufficient_function_decrease", C.c_double),
+                ("max_line_search_step_contraction", C.c_double),
+                ("min_line_search_step_contraction", C.c_double),
+                ("min_line_search_step_size", C.c_double)]
 
 
 class LmSummary(C.Structure):
@@ -67,7 +73,8 @@ class LmSummary(C.Structure):
                 ("num_successful_steps", C.c_int), ("num_evaluations", C.c_int),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("final_gradient_max_norm", C.c_double), ("final_radius", C.c_double),
-                ("seconds_total", C.c_double), ("seconds_eval", C.c_double)]
+                ("seconds_total", C.c_double), ("seconds_eval", C.c_double),
+                ("num_line_search_steps", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
@@ -95,6 +102,8 @@ SIGNATURES = {
                                         C.c_double, _dp]),
     "sba_problem_eval_timed": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                          C.c_double, C.c_int, _dp, _dp, _dp]),
+    "sba_problem_eval_launch_times": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
+                                                C.c_double, C.c_int, C.POINTER(C.c_float)]),
     "sba_problem_eval_steps": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                          C.c_double, C.c_int, _dp, _dp]),
     "sba_expand_pack": (C.c_int, [C.c_int, _dp, C.POINTER(NormalEq)]),
@@ -159,8 +168,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError here = header and library out of sync
         fn.restype = res
         fn.argtypes = args
-    if lib.sba_abi_version() != 1:
-        raise LibraryNotBuilt(f"{p}: ABI version {lib.sba_abi_version()} != 1, rebuild")
+    if lib.sba_abi_version() != ABI_VERSION:
+        raise LibraryNotBuilt(f"{p}: ABI version {lib.sba_abi_version()} != {ABI_VERSION}, rebuild")
     if path is None:
         _lib = lib
     return lib

@@ -36,6 +36,7 @@ class SolveSummary:
     final_radius: float
     seconds_total: float
     seconds_eval: float
+    num_line_search_steps: int = 0
 
 
 def _f64(a, shape=None) -> np.ndarray:
@@ -83,7 +84,8 @@ def _to_ne(ne: cabi.NormalEq) -> NormalEquations:
 def _summary(s: cabi.LmSummary) -> SolveSummary:
     return SolveSummary(cabi.TERMINATION.get(s.termination, str(s.termination)), s.num_iterations,
                         s.num_successful_steps, s.num_evaluations, s.initial_cost, s.final_cost,
-                        s.final_gradient_max_norm, s.final_radius, s.seconds_total, s.seconds_eval)
+                        s.final_gradient_max_norm, s.final_radius, s.seconds_total, s.seconds_eval,
+                        s.num_line_search_steps)
 
 
 class Problem:
@@ -198,6 +200,16 @@ class Problem:
                                                                d1, d2, huber_delta, repeat, _dptr(pack),
                                                                C.byref(step_ms), C.byref(sweep_ms)))
         return pack, step_ms.value, sweep_ms.value
+
+    def eval_launch_times(self, mode, rot, tran, d1=1.0, d2=1.0, huber_delta=1.0, depth_mode=DEPTH_UNIFORM,
+                          repeat: int = 20) -> np.ndarray:
+        """Device time (ms) of each of `repeat` back-to-back sweep-kernel launches (HIP event between every two)."""
+        rot, tran = _f64(rot, (3,)), _f64(tran, (3,))
+        ms = np.zeros(repeat, dtype=np.float32)
+        cabi.check(self._lib, self._lib.sba_problem_eval_launch_times(
+            self._h, mode, depth_mode, _dptr(rot), _dptr(tran), d1, d2, huber_delta, repeat,
+            ms.ctypes.data_as(C.POINTER(C.c_float))))
+        return ms.astype(np.float64)
 
     def eval_steps(self, mode, rot, tran, d1=1.0, d2=1.0, huber_delta=1.0, depth_mode=DEPTH_UNIFORM, steps: int = 1):
         """`steps` host-synchronous sweeps in a row inside the library; returns (last pack, seconds of the loop)."""

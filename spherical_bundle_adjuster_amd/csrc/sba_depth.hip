@@ -6,8 +6,11 @@
 // (.cpp:1060-1061) and no loss (.cpp:1059).  The Hessian is block diagonal, so the damped system of every LM
 // iteration splits into N independent 2x2 solves -- but radius, accept/reject, Jacobi scaling and the convergence
 // tests are global.  depth_step_kernel therefore does, for every match in one pass: residuals + 5x2 Jacobian at the
-// current depths, the scaled damped 2x2 solve, the projected candidate, the candidate's cost, and contributes to
-// the six global reductions the host needs for Ceres' step logic (sba_stages.cpp: sba_problem_solve_depths).
+// current depths, the scaled damped 2x2 solve (the step delta), the projected candidate P(d + alpha delta), the
+// candidate's cost and gradient, and contributes to the nine global reductions the host needs for Ceres' step logic
+// and its projected Armijo line search (sba_stages.cpp: sba_problem_solve_depths; the problem is bounds-constrained,
+// so Ceres line-searches every step).  alpha = 1 is the trust-region step and at the same time the line search's
+// first trial; a contraction re-runs the pass with alpha < 1 and the stored diagonal (same delta, bit for bit).
 // Two matches per lane, 16-byte accesses (1 KiB per wave instruction) -- HBM-bound: 8-12 loads + 4-8 stores of
 // 8 B per match and iteration (96-128 B).
 #include "sba_device.hpp"
@@ -77,11 +80,11 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
                                                         double* __restrict__ sc1, double* __restrict__ sc2,
                                                         double* __restrict__ dg1, double* __restrict__ dg2,
                                                         DepthParams P, double* __restrict__ partials) {
-  __shared__ double red[4][8];
+  __shared__ double red[4][DEPTH_OUT_COUNT];
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
   const bool load_scale = !P.first_iteration, load_diag = P.reuse_diagonal != 0;
-  double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gmax = 0;
+  double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gdelta = 0, cand_gdelta = 0, gmax = 0, dmax = 0;
   size_t pr = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   DepthRegs<ST> cur, nxt;
   if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, dg1, dg2, load_scale, load_diag, pr);
@@ -127,10 +130,14 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
       const double A11 = __builtin_fma(D1, P.inv_radius, H11), A22 = __builtin_fma(D2, P.inv_radius, H22), A12 = H12;
       const double inv_det = 1.0 / (A11 * A22 - A12 * A12);
       const double y1 = (G2 * A12 - G1 * A22) * inv_det, y2 = (G1 * A12 - G2 * A11) * inv_det;
-      const double na = fmax(a + s1 * y1, 0.0), nb = fmax(b + s2 * y2, 0.0);   // Plus + projection onto d >= 0
+      const double dl1 = s1 * y1, dl2 = s2 * y2;                               // delta = step .* jacobi scaling
+      // Plus(d, alpha * delta) + projection onto d >= 0 (alpha = 1: the trust-region candidate)
+      const double na = fmax(a + P.alpha * dl1, 0.0), nb = fmax(b + P.alpha * dl2, 0.0);
       NA[h] = na; NB[h] = nb;
       const double f0 = nb * u - na * q0 + P.t[0], f1 = nb * v - na * q1 + P.t[1], f2 = nb * w - na * q2 + P.t[2];
       const double f4 = P.lambda * exp(-P.c * na), f5 = P.lambda * exp(-P.c * nb);
+      // gradient at the candidate (for the slope of the line-search function at alpha)
+      const double cg1 = -(q0 * f0 + q1 * f1 + q2 * f2) - P.c * f4 * f4, cg2 = (u * f0 + v * f1 + w * f2) - P.c * f5 * f5;
       if (valid) {     // the padding element of an odd-sized problem contributes nothing
         cost += 0.5 * (e0 * e0 + e1 * e1 + e2 * e2 + r4 * r4 + r5 * r5);
         // projected gradient norm of the bounded problem: |x - P(x - g)|_inf
@@ -139,6 +146,9 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
         step2 += (na - a) * (na - a) + (nb - b) * (nb - b);
         x2n += a * a + b * b;
         cand_cost += 0.5 * (f0 * f0 + f1 * f1 + f2 * f2 + f4 * f4 + f5 * f5);
+        gdelta += g1 * dl1 + g2 * dl2;
+        cand_gdelta += cg1 * dl1 + cg2 * dl2;
+        dmax = fmax(dmax, fmax(fabs(dl1), fabs(dl2)));
       } else {
         NA[h] = 0.0; NB[h] = 0.0;   // keep the padding zero
       }
@@ -150,57 +160,61 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
     pr = pn;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double r[6] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),
-                       wave_max(gmax)};
+  const double r[DEPTH_OUT_COUNT] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),
+                                     wave_sum(gdelta), wave_sum(cand_gdelta), wave_max(gmax), wave_max(dmax)};
   if (lane == 0)
-    for (int k = 0; k < 6; ++k) red[wave][k] = r[k];
+    for (int k = 0; k < DEPTH_OUT_COUNT; ++k) red[wave][k] = r[k];
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < DEPTH_OUT_COUNT) {
+    const bool is_max = threadIdx.x >= DEPTH_OUT_SUMS;
     double s = red[0][threadIdx.x];
-    for (int wv = 1; wv < 4; ++wv) s = threadIdx.x == 5 ? fmax(s, red[wv][5]) : s + red[wv][threadIdx.x];
-    partials[static_cast<size_t>(blockIdx.x) * 8 + threadIdx.x] = s;
+    for (int wv = 1; wv < 4; ++wv) s = is_max ? fmax(s, red[wv][threadIdx.x]) : s + red[wv][threadIdx.x];
+    partials[static_cast<size_t>(blockIdx.x) * DEPTH_ROW + threadIdx.x] = s;
   }
 }
 
-// [nblocks][8] -> out[8]: sums of slots 0..4 and the max of slot 5, in a fixed order.
-// With host_out (mapped pinned memory) the six results are also published to the host: stores, system-scope release,
+// [nblocks][16] -> out[9]: sums of slots 0..6 and the maxima of slots 7, 8, in a fixed order.
+// With host_out (mapped pinned memory) the nine results are also published to the host: stores, system-scope release,
 // then the sequence number in host_out[24] -- the host polls that word (same protocol as finalize_kernel).
-__global__ __launch_bounds__(384) void depth_finalize_kernel(const double* __restrict__ partials, int nblocks,
-                                                             double* __restrict__ out, double* __restrict__ host_out,
-                                                             unsigned long long seq, int gather_slot) {
+__global__ __launch_bounds__(64 * DEPTH_OUT_COUNT) void depth_finalize_kernel(const double* __restrict__ partials,
+                                                                              int nblocks, double* __restrict__ out,
+                                                                              double* __restrict__ host_out,
+                                                                              unsigned long long seq, int gather_slot) {
   // One wave per result: lane l folds rows l, l+64, ... (four independent loads in flight), then a butterfly over the
   // wave.  The rows were just written by other CUs, so the length of this kernel is load round trips, not arithmetic.
-  __shared__ double res[8];
+  __shared__ double res[DEPTH_ROW];
   const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const bool is_max = slot == 5;
+  const bool is_max = slot >= DEPTH_OUT_SUMS;
   double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
   int b = lane;
   for (; b + 192 < nblocks; b += 256) {
-    const double a0 = partials[static_cast<size_t>(b) * 8 + slot], a1 = partials[static_cast<size_t>(b + 64) * 8 + slot];
-    const double a2 = partials[static_cast<size_t>(b + 128) * 8 + slot], a3 = partials[static_cast<size_t>(b + 192) * 8 + slot];
+    const double a0 = partials[static_cast<size_t>(b) * DEPTH_ROW + slot], a1 = partials[static_cast<size_t>(b + 64) * DEPTH_ROW + slot];
+    const double a2 = partials[static_cast<size_t>(b + 128) * DEPTH_ROW + slot], a3 = partials[static_cast<size_t>(b + 192) * DEPTH_ROW + slot];
     if (is_max) { v0 = fmax(v0, a0); v1 = fmax(v1, a1); v2 = fmax(v2, a2); v3 = fmax(v3, a3); }
     else { v0 += a0; v1 += a1; v2 += a2; v3 += a3; }
   }
   for (; b < nblocks; b += 64) {
-    const double a0 = partials[static_cast<size_t>(b) * 8 + slot];
+    const double a0 = partials[static_cast<size_t>(b) * DEPTH_ROW + slot];
     v0 = is_max ? fmax(v0, a0) : v0 + a0;
   }
   const double s = is_max ? wave_max(fmax(fmax(v0, v1), fmax(v2, v3))) : wave_sum((v0 + v1) + (v2 + v3));
   if (lane == 0) res[slot] = s;
   __syncthreads();
   if (gather_slot >= 0) {
-    // Sharded problem: `out` is the 24-double pack a SUM all-reduce follows on.  Slots 0..4 carry the five sums; the
-    // maximum cannot be summed, so every rank deposits its own in slot 8 + rank (zeros elsewhere) -- after the
-    // all-reduce every rank holds all of them and takes the maximum on the host.
-    if (threadIdx.x < 24)
-      out[threadIdx.x] = threadIdx.x < 5 ? res[threadIdx.x] : (static_cast<int>(threadIdx.x) == 8 + gather_slot ? res[5] : 0.0);
+    // Sharded problem: `out` is the 24-double pack a SUM all-reduce follows on.  Slots 0..6 carry the seven sums; a
+    // maximum cannot be summed, so every rank deposits its own two in slots 8 + rank and 16 + rank (zeros elsewhere)
+    // -- after the all-reduce every rank holds all of them and takes the maxima on the host.
+    if (threadIdx.x < 24) {
+      const int t = static_cast<int>(threadIdx.x);
+      out[t] = t < DEPTH_OUT_SUMS ? res[t] : (t == 8 + gather_slot ? res[DEPTH_OUT_GMAX] : (t == 16 + gather_slot ? res[DEPTH_OUT_DMAX] : 0.0));
+    }
     return;
   }
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < DEPTH_OUT_COUNT) {
     out[threadIdx.x] = res[threadIdx.x];
     if (host_out) host_out[threadIdx.x] = res[threadIdx.x];
   }
-  if (host_out && threadIdx.x < 64) {     // wave 0 holds all six host stores
+  if (host_out && threadIdx.x < 64) {     // wave 0 holds all nine host stores
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0)
@@ -219,7 +233,7 @@ hipError_t depth_blocks_per_cu(int store, int* blocks) {
 
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
-                             const DepthParams& prm, double* partials, int grid, double* out8, double* host_out,
+                             const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream) {
   if (grid > 0) {
     if (store == 0)
@@ -231,8 +245,8 @@ hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, cons
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(384), 0, stream, partials, grid, out8, host_out, seq,
-                     gather_slot);
+  hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(64 * DEPTH_OUT_COUNT), 0, stream, partials, grid, out,
+                     host_out, seq, gather_slot);
   return hipGetLastError();
 }
 

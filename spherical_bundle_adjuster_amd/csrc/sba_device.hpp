@@ -142,20 +142,33 @@ struct DepthParams {
   double lambda, c;
   double radius, inv_radius;
   double min_diagonal, max_diagonal;
+  double alpha;          // line-search step size: the candidate is P(d + alpha * delta); 1.0 for the trust-region step
   int first_iteration;   // compute and store the Jacobi scaling
-  int reuse_diagonal;    // previous step was rejected: keep the stored LM diagonal
+  int reuse_diagonal;    // previous step was rejected (or a line-search pass): keep the stored LM diagonal
   int jacobi_scaling;
   int pad_;
   unsigned long long n;
 };
-// gather_slot >= 0 (sharded problem): out8 is a 24-double pack for a SUM all-reduce, sums in [0..4], this rank's
-// gradient max-norm in [8 + gather_slot], zeros elsewhere; nothing is published to the host.
-// out8: [0] cost at d, [1] model cost change, [2] cost at candidate, [3] |step|^2, [4] |d|^2, [5] projected
-// gradient max-norm at d.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.
+// Results of one pass (DEPTH_OUT_* slots of out / host_out): seven sums and two maxima.
+enum {
+  DEPTH_OUT_COST = 0,       // cost at d
+  DEPTH_OUT_MODEL = 1,      // model cost change of the trust-region step delta
+  DEPTH_OUT_CAND_COST = 2,  // cost at the candidate P(d + alpha delta)
+  DEPTH_OUT_STEP2 = 3,      // |candidate - d|^2
+  DEPTH_OUT_X2 = 4,         // |d|^2
+  DEPTH_OUT_GDELTA = 5,     // gradient(d) . delta                         (line search: initial slope)
+  DEPTH_OUT_CAND_GDELTA = 6,// gradient(candidate) . delta                 (line search: slope at the trial point)
+  DEPTH_OUT_GMAX = 7,       // max: projected gradient max-norm at d
+  DEPTH_OUT_DMAX = 8,       // max: |delta|_inf
+  DEPTH_OUT_SUMS = 7, DEPTH_OUT_COUNT = 9, DEPTH_ROW = 16
+};
+// gather_slot >= 0 (sharded problem): `out` is a 24-double pack for a SUM all-reduce, the sums in [0..6], this rank's
+// two maxima in [8 + gather_slot] and [16 + gather_slot] (gather_slot < 8), zeros elsewhere; nothing is published to
+// the host.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.  partials: [grid][16].
 hipError_t depth_blocks_per_cu(int store, int* blocks);   // resident 256-thread blocks per CU of depth_step_kernel
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
-                             const DepthParams& prm, double* partials, int grid, double* out8, double* host_out,
+                             const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream);
 
 // 8-point initial guess, device part (.cpp:53-68): A^T A of the kron(left, right) rows for 64 interleaved groups.

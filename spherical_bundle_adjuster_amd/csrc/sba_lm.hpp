@@ -10,7 +10,8 @@
 //   - D^2 = clamp(diag(H_s), 1e-6, 1e32) / radius, kept across rejected steps
 //   - step quality rho = (cost - cost_candidate) / model_cost_change; accept if rho > 1e-3
 //   - accepted: radius /= max(1/3, 1 - (2 rho - 1)^3); rejected: radius /= nu, nu *= 2
-//   - stop on parameter / function / gradient tolerance, max iterations, min radius
+//   - stop on parameter / function tolerance inside an iteration; after it on the iteration limit, the gradient
+//     tolerance, the minimum radius (in that order, as Ceres checks them)
 //   - additive update of the angle-axis vector (no manifold is set anywhere in the reference)
 // One device sweep per LM iteration: the candidate point is evaluated with its Jacobian terms, so an
 // accepted step needs no second sweep (and a multi-GPU run needs one all-reduce per iteration).
@@ -47,6 +48,11 @@ inline void lm_default_options(sba_lm_options* o) {
   o->huber_delta = 1.0;
   o->tran_param = SBA_TRAN_FREE;
   o->verbose = 0;
+  o->max_num_line_search_step_size_iterations = 20;
+  o->line_search_sufficient_function_decrease = 1e-4;
+  o->max_line_search_step_contraction = 1e-3;
+  o->min_line_search_step_contraction = 0.6;
+  o->min_line_search_step_size = 1e-9;
 }
 
 // pack (SBA_PACK_* layout) -> symmetric 6x6 over [rot | tran]
@@ -247,7 +253,6 @@ class LmSolver {
       if (o_.verbose)
         std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n"
                     "%4d % .6e    0.00e+00    %.2e   0.00e+00   0.00e+00  %.2e\n", 0, cur_.cost, gmax_, radius_);
-      if (gmax_ <= o_.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, SBA_OK); return; }
       phase_ = kCandidate;
       next_candidate();
       return;
@@ -284,7 +289,6 @@ class LmSolver {
       radius_ = std::min(o_.max_trust_region_radius, radius_ / std::max(1.0 / 3.0, 1.0 - t3 * t3 * t3));
       decrease_ = 2.0;
       reuse_diagonal_ = false;
-      if (gmax_ <= o_.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, SBA_OK); return; }
     } else {
       radius_ /= decrease_; decrease_ *= 2.0; reuse_diagonal_ = true;
     }
@@ -314,10 +318,12 @@ class LmSolver {
     using namespace detail;
     const int m = par_.m;
     for (;;) {
-      ++iter_;
-      if (iter_ > o_.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, SBA_OK); return; }
+      // Ceres' end-of-iteration checks (FinalizeIterationAndCheckIfMinimizerCanContinue), in its order: iteration
+      // limit, gradient tolerance, minimum radius -- after iteration 0 and after every (valid or invalid) step.
+      if (iter_ >= o_.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, SBA_OK); return; }
+      if (gmax_ <= o_.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, SBA_OK); return; }
       if (radius_ < o_.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, SBA_OK); return; }
-      sum_.num_iterations = iter_;
+      sum_.num_iterations = ++iter_;
       double Hs[36], gs[6], A[36], rhs[6], y[6];
       for (int i = 0; i < m; ++i) {
         gs[i] = scale_[i] * gf_[i];

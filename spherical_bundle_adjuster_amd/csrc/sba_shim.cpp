@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -53,12 +54,25 @@ namespace sba {
 int host_threads() { return g_host_threads.load(); }
 int wait_for_sequence(const volatile unsigned long long* flag, unsigned long long seq, hipStream_t stream,
                       const char* what) {
+  // Wall-clock bound (SBA_WAIT_TIMEOUT_S, default 60 s): a device that never publishes -- a wedged kernel keeps the
+  // stream at hipErrorNotReady for ever -- must come back as an error, not as a spinning host thread.
+  static const double limit_s = [] {
+    const char* env = std::getenv("SBA_WAIT_TIMEOUT_S");
+    const double v = env ? std::atof(env) : 60.0;
+    return v > 0.0 ? v : 60.0;
+  }();
+  std::chrono::steady_clock::time_point t0;
+  bool timing = false;
   for (unsigned long spins = 0; *flag != seq; ++spins) {
     if ((spins & 0xfff) == 0xfff) {
       const hipError_t q = hipStreamQuery(stream);
       if (q != hipSuccess && q != hipErrorNotReady)
         return set_error(SBA_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
       if (q == hipSuccess && *flag != seq) return set_error(SBA_ERR_HIP, "%s finished without publishing its result", what);
+      const auto now = std::chrono::steady_clock::now();
+      if (!timing) { t0 = now; timing = true; }
+      else if (std::chrono::duration<double>(now - t0).count() > limit_s)
+        return set_error(SBA_ERR_HIP, "%s: no result from the device after %.0f s (SBA_WAIT_TIMEOUT_S)", what, limit_s);
     }
     __builtin_ia32_pause();
   }
@@ -324,7 +338,14 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   if (device < 0 || device >= count)
     return fail(SBA_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, count);
   SBA_HIP_TRY(hipSetDevice(device));
-  sba_problem* p = new sba_problem();
+  // Owned until the very end: any failing HIP call below releases whatever was created so far (sba_problem_destroy
+  // copes with a partially built handle -- every member starts out null).
+  struct Guard {
+    sba_problem* p;
+    ~Guard() { if (p) (void)sba_problem_destroy(p); }
+  } guard{new (std::nothrow) sba_problem()};
+  sba_problem* p = guard.p;
+  if (!p) return fail(SBA_ERR_HIP, "out of host memory");
   p->device = device;
   hipDeviceProp_t prop;
   SBA_HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -362,6 +383,7 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   if (const char* env = std::getenv("SBA_PUBLISH")) p->publish = std::strcmp(env, "0") != 0;
   SBA_HIP_TRY(hipEventCreate(&p->ev0));
   SBA_HIP_TRY(hipEventCreate(&p->ev1));
+  guard.p = nullptr;     // hand over
   *out = p;
   return SBA_OK;
 }
@@ -369,7 +391,7 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
 int sba_problem_destroy(sba_problem* p) {
   if (!p) return SBA_OK;
   (void)hipSetDevice(p->device);
-  (void)hipStreamSynchronize(p->stream);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm) {
     Rccl& r = rccl();
     if (r.ok) r.CommDestroy(p->comm);
@@ -607,6 +629,42 @@ int sba_problem_eval_timed(sba_problem* p, int mode, int depth_mode, const doubl
   SBA_HIP_TRY(hipEventSynchronize(p->ev1));
   SBA_HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   if (mean_step_ms) *mean_step_ms = static_cast<double>(ms) / repeat;
+  return SBA_OK;
+}
+
+int sba_problem_eval_launch_times(sba_problem* p, int mode, int depth_mode, const double rot[3],
+                                  const double tran[3], double d1, double d2, double huber_delta,
+                                  int repeat, float* launch_ms) {
+  int rc = check_args(p, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (!launch_ms || repeat < 1 || repeat > 4096) return fail(SBA_ERR_INVALID_ARG, "bad launch_ms/repeat (1..4096)");
+  SBA_HIP_TRY(hipSetDevice(p->device));
+  sba::SweepParams prm;
+  make_params(p, depth_mode, rot, tran, d1, d2, huber_delta, &prm);
+  make_frame(p, mode, rot);
+  int grid = 0;
+  rc = grid_for(p, mode, depth_mode, prm.delta > 0.0, &grid);
+  if (rc) return rc;
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+  sba::SweepOut out;
+  out.partials = p->partials; out.pack_dev = p->pack_dev; out.pack_host = nullptr; out.ticket = nullptr; out.seq = 0;
+  // one event between every two launches: launch i runs between events i and i + 1
+  struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+  } events;
+  events.ev.assign(static_cast<size_t>(repeat) + 1, nullptr);
+  for (hipEvent_t& e : events.ev) SBA_HIP_TRY(hipEventCreate(&e));
+  SBA_HIP_TRY(hipEventRecord(events.ev[0], p->stream));
+  for (int i = 0; i < repeat; ++i) {
+    SBA_HIP_TRY(sba::launch_sweep(mode, depth_mode, p->store, p->kind, pl, prm, out, grid, p->stream));
+    SBA_HIP_TRY(hipEventRecord(events.ev[static_cast<size_t>(i) + 1], p->stream));
+  }
+  SBA_HIP_TRY(hipEventSynchronize(events.ev[static_cast<size_t>(repeat)]));
+  for (int i = 0; i < repeat; ++i)
+    SBA_HIP_TRY(hipEventElapsedTime(&launch_ms[i], events.ev[static_cast<size_t>(i)], events.ev[static_cast<size_t>(i) + 1]));
   return SBA_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "sba_epipolar.hpp"
+#include "sba_line_search.hpp"
 #include "sba_lm.hpp"
 #include "sba_problem.hpp"
 #include "sba_rotation.hpp"
@@ -23,11 +24,11 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   if (!p || !rot || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
   if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   if (!p->has_d12 && p->n > 0) return sba::set_error(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
-  // Sharded problem: the six global reductions of every pass are all-reduced over the attached transport (the
-  // maximum travels as one slot per rank, so at most 16 shards), and every rank replays the same step logic.
+  // Sharded problem: the nine global reductions of every pass are all-reduced over the attached transport (the two
+  // maxima travel as one slot per rank each, so at most 8 shards), and every rank replays the same step logic.
   const bool collective = p->comm != nullptr || p->hook != nullptr || p->peer_ready;
-  if (collective && (p->shard_count < 1 || p->shard_count > 16 || p->shard_rank < 0 || p->shard_rank >= p->shard_count))
-    return sba::set_error(SBA_ERR_UNSUPPORTED, "d-only stage over a transport needs 1..16 shards (sba_problem_set_shard); have %d/%d",
+  if (collective && (p->shard_count < 1 || p->shard_count > 8 || p->shard_rank < 0 || p->shard_rank >= p->shard_count))
+    return sba::set_error(SBA_ERR_UNSUPPORTED, "d-only stage over a transport needs 1..8 shards (sba_problem_set_shard); have %d/%d",
                 p->shard_rank, p->shard_count);
   SBA_TRY_HIP(hipSetDevice(p->device));
   sba_lm_options o;
@@ -38,9 +39,12 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   const auto t_start = std::chrono::steady_clock::now();
   const size_t n = p->n, elems = std::max<size_t>(p->plane_elems, 2);
 
-  // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, 8 results
+  // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, results.  Zeroed once:
+  // the kernel writes whole pairs only, and a candidate plane becomes the problem's depth plane when a step is accepted
+  // -- its padding must be zeros like the uploaded planes' (a later per-match sweep loads it in its ragged tail).
   sba::DeviceBuffer work_buf, partials_buf, out_buf;
   SBA_TRY_HIP(work_buf.alloc(6 * elems * sizeof(double)));
+  SBA_TRY_HIP(hipMemsetAsync(work_buf.ptr, 0, 6 * elems * sizeof(double), p->stream));
   double* work = work_buf.as<double>();
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
          *dg2 = work + 5 * elems;
@@ -54,8 +58,8 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   if (const char* env = std::getenv("SBA_DEPTH_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) cap = v; }
   const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256,
                                                      static_cast<size_t>(p->num_cus) * std::max(1, std::min(occ, cap))));
-  SBA_TRY_HIP(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * 8 * sizeof(double)));
-  SBA_TRY_HIP(out_buf.alloc(8 * sizeof(double)));
+  SBA_TRY_HIP(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * sba::DEPTH_ROW * sizeof(double)));
+  SBA_TRY_HIP(out_buf.alloc(sba::DEPTH_ROW * sizeof(double)));
   double *partials = partials_buf.as<double>(), *out_dev = out_buf.as<double>();
 
   sba::Planes pl;
@@ -74,9 +78,13 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   double radius = o.initial_trust_region_radius, nu = 2.0;
   bool reuse = false, first = true;
   int invalid = 0, rc_final = SBA_OK;
-  double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto step = [&]() -> int {   // one device pass at the current depths
-    prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = reuse ? 1 : 0;
+  double out[sba::DEPTH_OUT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // One device pass at the current depths: the step delta of the damped system, the candidate P(d + alpha delta)
+  // into (c1, c2), and the nine reductions.  keep_diagonal: use the stored LM diagonal (after a rejected step, and
+  // for every line-search pass, whose delta must be the trust-region step's).
+  auto pass = [&](double alpha, bool keep_diagonal) -> int {
+    prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.alpha = alpha;
+    prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = keep_diagonal ? 1 : 0;
     if (collective) {
       SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
                                          p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
@@ -85,9 +93,12 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
       double raw[SBA_PACK_SIZE];
       rc = fetch_pack_raw(p, raw);
       if (rc) return rc;
-      for (int k = 0; k < 5; ++k) out[k] = raw[k];
-      out[5] = 0.0;
-      for (int r = 0; r < p->shard_count; ++r) out[5] = std::max(out[5], raw[8 + r]);
+      for (int k = 0; k < sba::DEPTH_OUT_SUMS; ++k) out[k] = raw[k];
+      out[sba::DEPTH_OUT_GMAX] = out[sba::DEPTH_OUT_DMAX] = 0.0;
+      for (int r = 0; r < p->shard_count; ++r) {
+        out[sba::DEPTH_OUT_GMAX] = std::max(out[sba::DEPTH_OUT_GMAX], raw[8 + r]);
+        out[sba::DEPTH_OUT_DMAX] = std::max(out[sba::DEPTH_OUT_DMAX], raw[16 + r]);
+      }
       sum->num_evaluations++;
       first = false;
       return SBA_OK;
@@ -103,7 +114,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     } else {
       SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
                                          out_dev, nullptr, 0, -1, p->stream));
-      SBA_TRY_HIP(hipMemcpyAsync(p->pack_host, out_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      SBA_TRY_HIP(hipMemcpyAsync(p->pack_host, out_dev, sizeof(out), hipMemcpyDeviceToHost, p->stream));
       SBA_TRY_HIP(hipStreamSynchronize(p->stream));
     }
     std::memcpy(out, p->pack_host, sizeof(out));
@@ -116,27 +127,47 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   };
 
-  for (int it = 1;; ++it) {
-    int rc = step();
+  for (int it = 0;;) {     // `it` = trust-region iterations completed
+    int rc = pass(1.0, reuse);
     if (rc) return rc;
-    const double cost = out[0], model = out[1], cand_cost = out[2], gmax = out[5];
-    if (it == 1) {
+    const double cost = out[sba::DEPTH_OUT_COST], model = out[sba::DEPTH_OUT_MODEL], gmax = out[sba::DEPTH_OUT_GMAX];
+    if (it == 0) {
       sum->initial_cost = cost;
       if (!std::isfinite(cost)) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
     }
-    // Ceres checks the gradient tolerance after every successful step (and at iteration 0): the gradient at the
-    // current point arrives with this pass.
-    if (!reuse && gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cost, gmax); break; }
-    if (it > o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cost, gmax); break; }
+    // Ceres' end-of-iteration checks, in its order (the gradient at the current point arrives with this pass)
+    if (it >= o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cost, gmax); break; }
+    if (gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cost, gmax); break; }
     if (radius < o.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, cost, gmax); break; }
-    sum->num_iterations = it;
+    sum->num_iterations = ++it;
     if (!(model > 0.0)) {
       if (++invalid >= 5) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
       radius /= nu; nu *= 2.0; reuse = true;
       continue;
     }
     invalid = 0;
-    if (std::sqrt(out[3]) <= o.parameter_tolerance * (std::sqrt(out[4]) + o.parameter_tolerance)) {
+    const double x2n = out[sba::DEPTH_OUT_X2];
+    if (o.max_num_line_search_step_size_iterations > 0) {
+      // Ceres' DoLineSearch (bounds-constrained problem): the pass above already holds the first trial (alpha = 1);
+      // a contraction re-runs it at the step size the search asks for, with the same delta.
+      sba::ls::ArmijoSearch search;
+      search.start(o, cost, out[sba::DEPTH_OUT_GDELTA], out[sba::DEPTH_OUT_DMAX]);
+      search.feed(out[sba::DEPTH_OUT_CAND_COST], out[sba::DEPTH_OUT_CAND_GDELTA]);
+      double planes_alpha = 1.0;     // the step size the candidate planes / out[] currently belong to
+      while (!search.done()) {
+        planes_alpha = search.query();
+        rc = pass(planes_alpha, true);
+        if (rc) return rc;
+        search.feed(out[sba::DEPTH_OUT_CAND_COST], out[sba::DEPTH_OUT_CAND_GDELTA]);
+      }
+      sum->num_line_search_steps += search.num_iterations();
+      if (search.step_size() != planes_alpha) {     // failed search: Ceres keeps the full step
+        rc = pass(search.step_size(), true);
+        if (rc) return rc;
+      }
+    }
+    const double cand_cost = out[sba::DEPTH_OUT_CAND_COST];
+    if (std::sqrt(out[sba::DEPTH_OUT_STEP2]) <= o.parameter_tolerance * (std::sqrt(x2n) + o.parameter_tolerance)) {
       finish(SBA_TERM_CONVERGENCE_PARAMETER, cost, gmax); break;
     }
     const double change = cost - cand_cost;

@@ -22,12 +22,16 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_defaults():
     lib = cabi.load_library()
-    assert lib.sba_abi_version() == 1
+    assert lib.sba_abi_version() == 2
     o = api.default_lm_options()
     # Ceres defaults + the reference's max_num_iterations = 50 (.cpp:336) and HuberLoss(1.0)
     assert (o.max_num_iterations, o.initial_trust_region_radius, o.min_relative_decrease) == (50, 1e4, 1e-3)
     assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
     assert o.huber_delta == 1.0 and o.jacobi_scaling == 1 and o.tran_param == api.TRAN_FREE
+    # Ceres' line-search defaults, which govern the bounded d-only stage (the reference sets none of them)
+    assert o.max_num_line_search_step_size_iterations == 20 and o.line_search_sufficient_function_decrease == 1e-4
+    assert (o.max_line_search_step_contraction, o.min_line_search_step_contraction) == (1e-3, 0.6)
+    assert o.min_line_search_step_size == 1e-9
 
 
 def test_expand_pack_host_only():

@@ -246,6 +246,72 @@ def test_depth_stage_matches_oracle(oracle, n, store):
         assert_normal_eq_close(got, ref, 1e-8, "after depth stage")
 
 
+# Ceres line-searches every step of this bounds-constrained stage (max_num_line_search_step_size_iterations = 20 by
+# default, reference .cpp:334-338 + :1060-1061).  Starts / regularisers whose full step fails the Armijo test, so that
+# contraction passes really run (tests/test_depth_line_search_cpu.py pins the same cases oracle-vs-numpy on the CPU).
+LS_CASES = [(500, 6, 1.0, 1.0, 1.0), (400, 9, 0.05, 1.0, 1.0), (300, 11, 0.01, 1.0, 1.0), (64, 21, 0.05, 5.0, 3.0),
+            (64, 23, 0.01, 20.0, 4.0), (64, 24, 0.2, 3.0, 8.0), (100003, 6, 1.0, 1.0, 1.0)]
+
+
+@pytest.mark.parametrize("n,seed,d0,lam,c", LS_CASES)
+@pytest.mark.parametrize("ls", [20, 0], ids=["ceres_default", "no_line_search"])
+def test_depth_stage_line_search_matches_oracle(oracle, n, seed, d0, lam, c, ls):
+    cs = synthetic.full_rt(n, seed=seed)
+    start = np.full((n, 2), d0)
+    dref, sref, rc = oracle.depth_solve(cs.x1, cs.x2, cs.rot_init, cs.tran_init, start, lam=lam, c=c,
+                                        options=oracle.default_options(max_num_line_search_step_size_iterations=ls))
+    assert rc == 0
+    with api.Problem(0) as p:
+        p.upload(cs.x1, cs.x2, start)
+        d, s = p.solve_depths(cs.rot_init, cs.tran_init, lam=lam, c=c,
+                              options=api.default_lm_options(max_num_line_search_step_size_iterations=ls))
+    assert (s.num_iterations, s.num_successful_steps, s.num_line_search_steps) == \
+        (sref.num_iterations, sref.num_successful_steps, sref.num_line_search_steps)
+    if ls and n <= 500:
+        assert s.num_line_search_steps >= 1            # the contraction path really ran on the device
+    assert s.termination == {1: "CONVERGENCE_FUNCTION", 2: "CONVERGENCE_GRADIENT", 3: "CONVERGENCE_PARAMETER",
+                             4: "NO_CONVERGENCE"}[sref.termination]
+    assert np.abs(d - dref).max() <= 1e-7 * max(1.0, np.abs(dref).max()) and (d >= 0).all()
+    assert abs(s.final_cost - sref.final_cost) <= 1e-10 * sref.final_cost
+
+
+def test_depth_stage_line_search_failure_keeps_full_step(oracle):
+    """A search that cannot succeed (sufficient decrease 1 - 1e-12 can only be met by an exactly linear cost) leaves the
+    step unscaled after the allowed contractions, like Ceres (`if (line_search_summary.success) delta *= ...`): the
+    candidate planes are restored by one more pass at step size 1."""
+    cs = synthetic.full_rt(257, seed=6)
+    start = np.ones((257, 2))
+    kw = dict(max_num_line_search_step_size_iterations=3, line_search_sufficient_function_decrease=1.0 - 1e-12,
+              max_num_iterations=4)
+    dref, sref, rc = oracle.depth_solve(cs.x1, cs.x2, cs.rot_init, cs.tran_init, start, options=oracle.default_options(**kw))
+    with api.Problem(0) as p:
+        p.upload(cs.x1, cs.x2, start)
+        d, s = p.solve_depths(cs.rot_init, cs.tran_init, options=api.default_lm_options(**kw))
+    assert sref.num_line_search_steps >= 3
+    assert (s.num_iterations, s.num_successful_steps, s.num_line_search_steps) == \
+        (sref.num_iterations, sref.num_successful_steps, sref.num_line_search_steps)
+    assert np.abs(d - dref).max() <= 1e-9 * max(1.0, np.abs(dref).max())
+
+
+@pytest.mark.parametrize("n", [5, 6, 4097, 4098])
+def test_depth_stage_f32_planes_ragged_tail_stays_clean(oracle, n):
+    """f32 coordinate planes hold 4 matches per 16-byte vector, the depth planes 2: with n % 4 in {1, 2} the last sweep
+    vector reaches past the last depth pair.  After an ODD number of accepted steps the candidate planes are the
+    problem's depth planes -- their padding must be zero like an uploaded plane's, or a per-match sweep turns NaN."""
+    cs = synthetic.full_rt(n, seed=77)
+    x1, x2 = cs.x1.astype(np.float32).astype(np.float64), cs.x2.astype(np.float32).astype(np.float64)
+    for max_it in (1, 2, 3):                       # odd and even numbers of accepted steps
+        start = np.full((n, 2), 3.0)
+        with api.Problem(0) as p:
+            p.upload(cs.x1, cs.x2, start, store=api.STORE_F32)
+            d, s = p.solve_depths(cs.rot_init, cs.tran_init, options=api.default_lm_options(max_num_iterations=max_it))
+            assert s.num_successful_steps == max_it
+            got = p.eval(api.MODE_RT, cs.rot_init, cs.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        ref = oracle.evaluate(2, x1, x2, cs.rot_init, cs.tran_init, d12=d)
+        assert np.isfinite(got.H).all() and np.isfinite(got.g).all() and np.isfinite(got.cost)
+        assert_normal_eq_close(got, ref, 1e-10, f"n={n} after {max_it} accepted steps")
+
+
 def test_depth_stage_errors():
     c = synthetic.rotation_only(10, seed=1)
     with api.Problem(0) as p:
