@@ -285,6 +285,12 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
 #define SBA_COMM_ID_BYTES 128
 int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]);
 int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]);
+/* 1 if librccl could be loaded and bound in this process (0: reason in sba_last_error).  ncclCommInitRank is itself
+ * a collective: a rank that cannot even load the library would leave the others waiting inside it, so ranks agree on
+ * this BEFORE any of them calls sba_problem_comm_init_rank.                                                        */
+int sba_rccl_available(void);
+/* Tear the communicator down again (after a rank reported failure: all ranks destroy theirs and fall back together). */
+int sba_problem_comm_destroy(sba_problem* p);
 /* Option C: direct peer exchange, no collective library on the data path.  Every rank owns a 4 KiB inbox in
  * fine-grained device memory that all peers map through HIP IPC; per sweep one wave stores its 24 doubles into every
  * peer's inbox (over xGMI), polls its own inbox and sums the nranks contributions in rank order (bit-identical on all
@@ -370,6 +376,14 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
 int sba_keypoints_to_sphere(int device, const void* keypoints, size_t n, size_t stride_bytes,
                             int im_width, int im_height, double* out_xyz);
 
+/* The four maps below end in a decision on an f64 expression of sin/cos/acos/atan2 -- an integer pixel index by
+ * truncation, or a float32 by rounding.  The device computes every output and marks the few whose f64 value lies within
+ * 1e-6 pixel of such a decision boundary (at pitch -90 whole pixel lines sit exactly on one); those are finished on the
+ * host by the same source function compiled against the host C library, the one the reference runs on.  Results are
+ * therefore bit-identical to the reference's arithmetic, not merely within a pixel.  The *_device forms take device
+ * pointers and a HIP stream (NULL = the default stream); they synchronise that stream once (to read the list of
+ * marked outputs) -- the image forms only the first time a geometry is seen, its source-index table is cached.     */
+
 /* ERP -> cubemap strip (equi2cube.cpp:12-302).  erp: H x W x 3 bytes (8UC3, row-major, host).
  * out: cube_size x (6*cube_size) x 3 bytes, face order left,front,right,back,top,bottom
  * (equi2cube.cpp:292-298).  Source indices are clamped into the image (the reference does not
@@ -377,7 +391,7 @@ int sba_keypoints_to_sphere(int device, const void* keypoints, size_t n, size_t 
 int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, int cube_size,
                   uint8_t* out);
 /* Batched, device-resident form: erp_dev = batch x H x W x 3 bytes, out_dev = batch x S x 6S x 3
- * bytes, both on `device`; enqueued on `stream` (NULL = the default stream), not synchronised.  */
+ * bytes, both on `device`; enqueued on `stream`.                                                 */
 int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
                          int cube_size, int batch, void* out_dev);
 
@@ -387,14 +401,24 @@ int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_h
  * through rotate_pixel (:48-74) with the reference's integer truncations, writes ERP pixel coordinates back. */
 int sba_rotate_keypoints(int device, void* keypoints, size_t n, size_t stride_bytes, float pitch_deg,
                          int im_width, int im_height);
+int sba_rotate_keypoints_device(int device, void* stream, void* keypoints_dev, size_t n, size_t stride_bytes,
+                                float pitch_deg, int im_width, int im_height);
 /* equi2cube_surf::cube2equi_pixel (equi2cube_surf.cpp:19-76): in place, cube-strip pixel -> ERP pixel.       */
 int sba_cube2equi_keypoints(int device, void* keypoints, size_t n, size_t stride_bytes, int cube_size,
                             int im_width, int im_height);
+int sba_cube2equi_keypoints_device(int device, void* stream, void* keypoints_dev, size_t n, size_t stride_bytes,
+                                   int cube_size, int im_width, int im_height);
 /* spherical_surf::crop_rotated_image (spherical_surf.cpp:76-108): erp H x W x 3 bytes -> out (H/4) x W x 3,
  * the equatorial band of the image rotated by pitch_deg (inverse warping); pixels whose source falls outside
  * the image are 0 (the reference leaves them uninitialised).                                               */
 int sba_crop_rotated_image(int device, const uint8_t* erp, int im_height, int im_width, float pitch_deg,
                            uint8_t* out);
+/* Batched, device-resident form: erp_dev = batch x H x W x 3, out_dev = batch x (H/4) x W x 3.               */
+int sba_crop_rotated_image_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
+                                  float pitch_deg, int batch, void* out_dev);
+/* Diagnostics: number of outputs of the cached source-index table that were decided on the host; -1 if that table has
+ * not been built.  kind 0 = equi2cube (param = cube_size), 1 = crop (param = the bit pattern of the float pitch).   */
+long sba_map_table_host_decided(int device, int kind, int param, int im_height, int im_width);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,8 @@ SIGNATURES = {
     "sba_problem_initial_guess": (C.c_int, [_vp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp, C.POINTER(C.c_int)]),
     "sba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sba_problem_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
+    "sba_rccl_available": (C.c_int, []),
+    "sba_problem_comm_destroy": (C.c_int, [_vp]),
     "sba_problem_peer_export": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "sba_problem_peer_connect": (C.c_int, [_vp, C.c_char_p]),
     "sba_problem_peer_selftest": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
@@ -139,6 +141,10 @@ SIGNATURES = {
     "sba_rotate_keypoints": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_int]),
     "sba_cube2equi_keypoints": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "sba_crop_rotated_image": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "sba_rotate_keypoints_device": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, C.c_int]),
+    "sba_cube2equi_keypoints_device": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "sba_crop_rotated_image_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
+    "sba_map_table_host_decided": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sba_equi2cube": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "sba_equi2cube_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
 }

@@ -262,6 +262,9 @@ class Problem:
             raise ValueError("unique_id must be 128 bytes")
         cabi.check(self._lib, self._lib.sba_problem_comm_init_rank(self._h, nranks, rank, unique_id))
 
+    def comm_destroy(self) -> None:
+        cabi.check(self._lib, self._lib.sba_problem_comm_destroy(self._h))
+
     def peer_export(self, nranks: int, rank: int) -> bytes:
         """Allocate this rank's inbox for the direct peer exchange; returns its 64-byte IPC handle."""
         buf = C.create_string_buffer(cabi.PEER_HANDLE_BYTES)
@@ -419,6 +422,11 @@ def initial_guess_from_moments(groups, trials: int = 80, subset_fraction: float 
     cabi.check(lib, lib.sba_initial_guess_from_moments(_dptr(g), trials, subset_fraction, seed, _dptr(e), _dptr(t),
                                                        C.byref(n)))
     return e, t, n.value
+
+
+def rccl_available() -> bool:
+    """librccl loadable and bound in this process (checked on every rank before anyone enters ncclCommInitRank)."""
+    return bool(cabi.load_library().sba_rccl_available())
 
 
 def comm_unique_id() -> bytes:

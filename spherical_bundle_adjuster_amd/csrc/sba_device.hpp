@@ -82,16 +82,20 @@ struct PeerInboxes {
   double* inbox[kMaxPeers];   // device-visible address of every rank's inbox (index = rank, own included)
   int nranks;
   int rank;
+  unsigned long long timeout_ticks;   // longest wait for a peer's slot, in ticks of the constant-rate wall clock
+                                      // (wall_clock64, hipDeviceAttributeWallClockRate) -- time, not loop iterations
+  unsigned long long* sticky;         // device word, set to 1 by any exchange that timed out and never cleared: a
+                                      // later exchange of the same burst publishes it, so no timeout goes unseen
 };
 hipError_t launch_peer_exchange(const double* pack_local, const PeerInboxes& px, unsigned long long xseq,
                                 double* pack_out, double* pack_host_dev, unsigned long long host_seq,
-                                unsigned long long spin_limit, hipStream_t stream);
+                                hipStream_t stream);
 // Folds partials[nblocks][kRow] into pack_out[24].  px != nullptr: the same launch then all-reduces the pack across
 // ranks (peer exchange, sequence number xseq).  pack_host_dev != nullptr: ... and publishes it to mapped pinned host
 // memory followed by `seq` at [24] for the host to poll.
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
                            unsigned long long seq, const PeerInboxes* px, unsigned long long xseq,
-                           unsigned long long spin_limit, hipStream_t stream);
+                           hipStream_t stream);
 
 // pack_dev[24] -> mapped pinned host memory, then `seq` at pack_host[24] (64-bit) for the host to poll.
 hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigned long long seq,
@@ -182,10 +186,6 @@ hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride
 // ... fused with the upload: matched key-point records of both images -> the six coordinate planes (x1.xyz, x2.xyz)
 hipError_t launch_keypoints_to_planes(const uint8_t* kp_left, const uint8_t* kp_right, size_t n, size_t stride_bytes,
                                       double im_w, double im_h, void* const planes[6], int store, hipStream_t stream);
-// ERP -> cubemap strip (equi2cube.cpp:12-302)
-hipError_t launch_equi2cube(const uint8_t* erp, int im_h, int im_w, int cube, int batch, uint8_t* out,
-                            hipStream_t stream);
-
 int points_per_lane(int store);  // 2 for f64 planes, 4 for f32 planes
 
 }  // namespace sba

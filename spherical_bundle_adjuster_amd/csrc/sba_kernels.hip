@@ -197,12 +197,14 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(Planes pl, SweepParams pr
 // -- every rank adds the same numbers in the same order, so all ranks obtain the bit-identical result -- and
 // (7) publish the pack to the host like publish_kernel.  Two parities: a rank can run at most one exchange ahead of
 // the slowest (it needs everybody's slot of round s before it can finish round s), so round s+1 never overwrites a
-// slot somebody still reads.  Spins are bounded; on a timeout word 25 of the host pack is set so the host reports
-// SBA_ERR_COMM instead of waiting forever.
+// slot somebody still reads.  Waits are bounded in TIME (px.timeout_ticks of the constant-rate wall clock); a timeout
+// sets the sticky device word px.sticky, and word 25 of the host pack carries that word with every publication, so the
+// host reports SBA_ERR_COMM -- also for a timeout in an earlier exchange of a back-to-back burst -- instead of waiting
+// forever or summing stale slots unnoticed.
 // The exchange as executed by ONE wave (lanes 0..23 hold the local pack in `v`); returns the all-reduced value for the
 // lane and whether every source rank arrived in time.
 __device__ __forceinline__ double peer_exchange_wave(double v, const PeerInboxes& px, unsigned long long seq,
-                                                     unsigned long long spin_limit, int lane, bool* all_ok) {
+                                                     int lane, bool* all_ok) {
   const unsigned parity = static_cast<unsigned>(seq & 1ull);
   const size_t my_slot = (static_cast<size_t>(parity) * kMaxPeers + px.rank) * 32;
   // (1) payload to every inbox (own included)
@@ -220,13 +222,17 @@ __device__ __forceinline__ double peer_exchange_wave(double v, const PeerInboxes
   if (lane < px.nranks) {
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(
         px.inbox[px.rank] + (static_cast<size_t>(parity) * kMaxPeers + lane) * 32 + 31);
-    unsigned long long spins = 0;
+    const long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if (++spins > spin_limit) { ok = false; break; }
+      if (static_cast<unsigned long long>(wall_clock64() - t0) > px.timeout_ticks) { ok = false; break; }
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  *all_ok = __ballot(!ok) == 0ull;
+  const bool timed_out = __ballot(!ok) != 0ull;
+  if (timed_out && lane == 0)
+    __hip_atomic_store(px.sticky, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // every exchange reports the sticky word, not just its own wait: an earlier timeout stays visible
+  *all_ok = !timed_out && __hip_atomic_load(px.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
   // (5)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   // (6) rank-ordered sum
@@ -261,11 +267,10 @@ __global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ 
 __global__ __launch_bounds__(64) void peer_exchange_kernel(const double* __restrict__ pack_local, PeerInboxes px,
                                                            unsigned long long seq, double* __restrict__ pack_out,
                                                            double* __restrict__ pack_host,
-                                                           unsigned long long host_seq,
-                                                           unsigned long long spin_limit) {
+                                                           unsigned long long host_seq) {
   const int lane = threadIdx.x;
   bool all_ok = true;
-  const double tot = peer_exchange_wave(lane < 24 ? pack_local[lane] : 0.0, px, seq, spin_limit, lane, &all_ok);
+  const double tot = peer_exchange_wave(lane < 24 ? pack_local[lane] : 0.0, px, seq, lane, &all_ok);
   if (lane < 24) pack_out[lane] = tot;
   if (pack_host) publish_wave(tot, pack_host, host_seq, all_ok, lane);
 }
@@ -278,8 +283,7 @@ __global__ __launch_bounds__(64) void peer_exchange_kernel(const double* __restr
 __global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict__ partials,
                                                         int nblocks, double* __restrict__ pack_out,
                                                         double* __restrict__ pack_host, unsigned long long seq,
-                                                        PeerInboxes px, unsigned long long xseq,
-                                                        unsigned long long spin_limit) {
+                                                        PeerInboxes px, unsigned long long xseq) {
   __shared__ double part[32][33];
   const int slot = threadIdx.x & 31, grp = threadIdx.x >> 5;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double* __restrict
     for (int g = 1; g < 32; ++g) tot += part[g][lane];
   }
   bool ok = true;
-  if (px.nranks > 0) tot = peer_exchange_wave(tot, px, xseq, spin_limit, lane, &ok);
+  if (px.nranks > 0) tot = peer_exchange_wave(tot, px, xseq, lane, &ok);
   if (lane < 24) pack_out[lane] = tot;
   if (pack_host) publish_wave(tot, pack_host, seq, ok, lane);
 }
@@ -366,21 +370,23 @@ hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigne
 
 hipError_t launch_peer_exchange(const double* pack_local, const PeerInboxes& px, unsigned long long xseq,
                                 double* pack_out, double* pack_host_dev, unsigned long long host_seq,
-                                unsigned long long spin_limit, hipStream_t stream) {
+                                hipStream_t stream) {
   hipLaunchKernelGGL(peer_exchange_kernel, dim3(1), dim3(64), 0, stream, pack_local, px, xseq, pack_out, pack_host_dev,
-                     host_seq, spin_limit);
+                     host_seq);
   return hipGetLastError();
 }
 
 hipError_t launch_finalize(const double* partials, int nblocks, double* pack_out, double* pack_host_dev,
                            unsigned long long seq, const PeerInboxes* px, unsigned long long xseq,
-                           unsigned long long spin_limit, hipStream_t stream) {
+                           hipStream_t stream) {
   PeerInboxes none;
   for (auto& q : none.inbox) q = nullptr;
   none.nranks = 0;
   none.rank = 0;
+  none.timeout_ticks = 0;
+  none.sticky = nullptr;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, nblocks, pack_out, pack_host_dev, seq,
-                     px ? *px : none, xseq, spin_limit);
+                     px ? *px : none, xseq);
   return hipGetLastError();
 }
 

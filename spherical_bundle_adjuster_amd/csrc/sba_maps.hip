@@ -1,10 +1,29 @@
-// Key-point / image coordinate maps of the reference's matchers: the pieces
-// of spherical_surf and equi2cube_surf that turn matcher output into the ERP key-points the BA path consumes.
-//   rotate_keypoints      spherical_surf::rotate_keypoint   (spherical_surf.cpp:110-123) via rotate_pixel (:48-74)
-//   crop_rotated_image    spherical_surf::crop_rotated_image (spherical_surf.cpp:76-108)
-//   cube2equi_keypoints   equi2cube_surf::cube2equi_pixel    (equi2cube_surf.cpp:19-76)
-// Integer pixel indices come from the same truncations as the reference (Vec2i), in f64 like the reference.
+// Key-point / image coordinate maps of the reference's matchers and of equi2cube (SURVEY.md section 8 rows a-9, f-3,
+// f-4): the pieces that turn ERP frames and matcher output into what the BA path consumes.
+//   equi2cube            equi2cube::get_* / get_all            (equi2cube.cpp:12-302)
+//   crop_rotated_image   spherical_surf::crop_rotated_image    (spherical_surf.cpp:76-108) via rotate_pixel (:48-74)
+//   rotate_keypoints     spherical_surf::rotate_keypoint       (spherical_surf.cpp:110-123) via rotate_pixel
+//   cube2equi_keypoints  equi2cube_surf::cube2equi_pixel       (equi2cube_surf.cpp:19-76)
+//
+// All four end in a DECISION taken on an f64 expression built from sin/cos/sqrt/acos/atan2: an integer pixel index by
+// truncation (`Vec2i = height * acos(..) / M_PI`), or a float32 by rounding.  The device's libm (ocml) and the
+// reference's (glibc) agree to a few ulp, which is invisible unless the f64 value sits within those few ulp of a
+// decision boundary -- and at pitch -90 deg, or for any pitch on some image sizes, whole lines of pixels sit EXACTLY on
+// integer boundaries (column 3W/4, the equator row), where the result follows the last bit.  Bit-exact results therefore
+// cannot come from the device alone.  Every kernel here computes the decision AND whether it is sensitive (the f64 value
+// within 1e-6 pixel of an integer -- six orders above the device/host discrepancy -- or the direction within 1e-4 rad
+// of a pole, where acos/atan2 amplify errors); the few sensitive outputs (typically 1e-5 .. 1e-4 of all, everything at
+// pitch 0) are finished on the host with the SAME source function compiled for the host, i.e. with the C library the
+// reference itself runs on.  This file is built with -ffp-contract=off: the reference's x86-64 arithmetic is unfused.
+//
+// The two image maps depend only on (geometry, H, W), not on pixel values: the source index of every output pixel is
+// computed once into a table (cached per device and geometry), and a frame -- or a batch of frames -- is then a pure
+// gather: 4 B of table (L2 / MALL resident across the batch) + one dword load + 3 B stored per output pixel.
+#include <algorithm>
 #include <cstring>
+#include <list>
+#include <mutex>
+#include <vector>
 
 #include "sba_internal.hpp"
 
@@ -12,60 +31,63 @@ namespace sba {
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
+constexpr double kTieTol = 1e-6;       // pixels: distance to the nearest integer below which the host decides
+constexpr double kPoleTol = 1e-8;      // sin^2(colatitude) below which the host decides
+constexpr double kFloatTol = 1e-11;    // relative: float32 rounding decided on the host when this close to a midpoint
 
 struct Rot3 { double m[9]; };
 
-// rotate_pixel (spherical_surf.cpp:48-74)
-__device__ __forceinline__ void rotate_pixel(int row, int col, const Rot3& R, int width, int height, int* out_row,
-                                             int* out_col) {
+struct PixelDecision { int row, col; bool sensitive; };
+
+// unit direction -> ERP pixel by truncation (spherical_surf.cpp:62-71, equi2cube.cpp:40-50)
+__host__ __device__ inline PixelDecision direction_to_pixel(double w0, double w1, double w2, int width, int height) {
+  const double a = acos(w2);
+  double b = atan2(w1, w0);
+  if (b < 0) b += kPi * 2;
+  const double ur = height * a / kPi, uc = width * b / (2 * kPi);
+  PixelDecision d;
+  d.row = static_cast<int>(ur);
+  d.col = static_cast<int>(uc);
+  d.sensitive = !(fabs(ur - rint(ur)) >= kTieTol) || !(fabs(uc - rint(uc)) >= kTieTol) || !(1.0 - w2 * w2 >= kPoleTol);
+  return d;
+}
+
+// rotate_pixel (spherical_surf.cpp:48-74): (row, col) -> sphere -> R -> (row, col)
+__host__ __device__ inline PixelDecision rotate_pixel(int row, int col, const Rot3& R, int width, int height) {
   const double r0 = kPi * row / height, r1 = 2 * kPi * col / width;
   const double s0 = sin(r0);
   const double v0 = s0 * cos(r1), v1 = s0 * sin(r1), v2 = cos(r0);
   const double w0 = R.m[0] * v0 + R.m[1] * v1 + R.m[2] * v2;
   const double w1 = R.m[3] * v0 + R.m[4] * v1 + R.m[5] * v2;
   const double w2 = R.m[6] * v0 + R.m[7] * v1 + R.m[8] * v2;
-  const double a = acos(w2);
-  double b = atan2(w1, w0);
-  if (b < 0) b += kPi * 2;
-  *out_row = static_cast<int>(height * a / kPi);
-  *out_col = static_cast<int>(width * b / (2 * kPi));
+  return direction_to_pixel(w0, w1, w2, width, height);
 }
 
-__global__ void rotate_keypoints_kernel(uint8_t* __restrict__ kp, size_t n, size_t stride, Rot3 R, int width,
-                                        int height) {
-  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float* rec = reinterpret_cast<float*>(kp + i * stride);
-  const float px = rec[0], py = rec[1];
-  const int offset_i = static_cast<int>(py + static_cast<float>(height * 3 / 8));   // .cpp:116
-  int r, c;
-  rotate_pixel(offset_i, static_cast<int>(px), R, width, height, &r, &c);
-  rec[0] = static_cast<float>(c);
-  rec[1] = static_cast<float>(r);
-}
-
-__global__ void crop_rotated_kernel(const uint8_t* __restrict__ im, int im_h, int im_w, Rot3 R,
-                                    uint8_t* __restrict__ out) {
-  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int rows = im_h / 4;
-  if (g >= static_cast<size_t>(rows) * im_w) return;
-  const int i = static_cast<int>(g / im_w), j = static_cast<int>(g % im_w);
-  int r, c;
-  rotate_pixel(i + im_h * 3 / 8, j, R, im_w, im_h, &r, &c);               // inverse warping, .cpp:91-96
-  uint8_t b0 = 0, b1 = 0, b2 = 0;                                          // outside: 0 (reference: uninitialised)
-  if (r >= 0 && c >= 0 && r < im_h && c < im_w) {                           // .cpp:100
-    const uint8_t* s = im + (static_cast<size_t>(r) * im_w + c) * 3;
-    b0 = s[0]; b1 = s[1]; b2 = s[2];
+// One output pixel of the cube strip (face order left, front, right, back, top, bottom; equi2cube.cpp:292-298).
+__host__ __device__ inline PixelDecision cube_pixel_source(int face, int i, int j, int S, int width, int height) {
+  const double s = static_cast<double>(S);
+  const double a = (s - 2.0 * j) / s, b = (s - 2.0 * i) / s;      // (cube_size - 2 j) / cube_size, ... i ...
+  const double an = (2.0 * j - s) / s, bn = (2.0 * i - s) / s;
+  double x, y, z;
+  switch (face) {
+    case 0: x = a;    y = 1.0;  z = b;    break;  // left   (equi2cube.cpp:118-120)
+    case 1: x = -1.0; y = a;    z = b;    break;  // front  (:73-75)
+    case 2: x = an;   y = -1.0; z = b;    break;  // right  (:163-165)
+    case 3: x = 1.0;  y = an;   z = b;    break;  // back   (:28-30)
+    case 4: x = b;    y = a;    z = 1.0;  break;  // top    (:208-210)
+    default: x = bn;  y = a;    z = -1.0; break;  // bottom (:253-255)
   }
-  uint8_t* d = out + g * 3;
-  d[0] = b0; d[1] = b1; d[2] = b2;
+  const double nrm = sqrt(x * x + y * y + z * z);
+  return direction_to_pixel(x / nrm, y / nrm, z / nrm, width, height);
 }
 
-__global__ void cube2equi_kernel(uint8_t* __restrict__ kp, size_t n, size_t stride, int S, int im_w, int im_h) {
-  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float* rec = reinterpret_cast<float*>(kp + i * stride);
-  const float cx = rec[0], cy = rec[1];
+// cube2equi_pixel (equi2cube_surf.cpp:19-76): cube-strip pixel (float) -> ERP pixel (float32 of an f64 expression)
+struct FloatDecision { float x, y; bool sensitive; };
+__host__ __device__ inline bool float_rounding_is_sensitive(double u) {
+  const float f = static_cast<float>(u);
+  return static_cast<float>(u * (1.0 + kFloatTol)) != f || static_cast<float>(u * (1.0 - kFloatTol)) != f || !(u == u);
+}
+__host__ __device__ inline FloatDecision cube2equi_pixel(float cx, float cy, int S, int width, int height) {
   const double s = S;
   double x = 0, y = 0, z = 0;
   if (cx < S) { x = (s - 2.0 * cx) / s; y = 1.0; z = (s - 2.0 * cy) / s; }                                       // left
@@ -75,11 +97,169 @@ __global__ void cube2equi_kernel(uint8_t* __restrict__ kp, size_t n, size_t stri
   else if (cx >= 4 * S && cx < 5 * S) { x = (s - 2.0 * cy) / s; y = (s - 2.0 * (cx - 4 * S)) / s; z = 1.0; }    // top
   else if (cx >= 5 * S) { x = (2.0 * cy - s) / s; y = (s - 2.0 * (cx - 5 * S)) / s; z = -1.0; }                 // bottom
   const double nrm = sqrt(x * x + y * y + z * z);
-  const double a = acos(z / nrm);
+  const double uz = z / nrm;
+  const double a = acos(uz);
   double b = atan2(y / nrm, x / nrm);
   if (b < 0) b += kPi * 2;
-  rec[0] = static_cast<float>(im_w * b / (2 * kPi));
-  rec[1] = static_cast<float>(im_h * a / kPi);
+  const double ux = width * b / (2 * kPi), uy = height * a / kPi;
+  FloatDecision d;
+  d.x = static_cast<float>(ux);
+  d.y = static_cast<float>(uy);
+  d.sensitive = float_rounding_is_sensitive(ux) || float_rounding_is_sensitive(uy) || !(1.0 - uz * uz >= kPoleTol) ||
+                !(fabs(b) >= 1e-9);     // b ~ 0: the sign test above may go either way
+  return d;
+}
+
+// rotate_keypoint's per-record work (spherical_surf.cpp:116-121): band offset, truncations, rotate_pixel
+__host__ __device__ inline PixelDecision rotate_keypoint_record(float px, float py, const Rot3& R, int width, int height) {
+  const int offset_i = static_cast<int>(py + static_cast<float>(height * 3 / 8));   // float + int, truncated (.cpp:116)
+  return rotate_pixel(offset_i, static_cast<int>(px), R, width, height);
+}
+
+// ---- sensitive-output list: device appends, host finishes ----------------------------------------------------------
+struct TieList {
+  unsigned int* count;      // device counter
+  unsigned int* index;      // [capacity] output indices
+  unsigned int capacity;
+};
+__device__ __forceinline__ void tie_append(const TieList& t, unsigned int idx) {
+  const unsigned int k = atomicAdd(t.count, 1u);
+  if (k < t.capacity) t.index[k] = idx;
+}
+
+// ---- source-index tables of the two image maps -----------------------------------------------------------------------
+// table[o] = source pixel index of output pixel o, or -1 where the source falls outside the image (crop only).
+__global__ __launch_bounds__(256) void equi2cube_table_kernel(int S, int im_h, int im_w, int* __restrict__ table, TieList ties) {
+  const size_t o = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= static_cast<size_t>(S) * 6 * S) return;
+  const int i = static_cast<int>(o / (6 * S)), c = static_cast<int>(o % (6 * S));
+  const int face = c / S, j = c - face * S;
+  const PixelDecision d = cube_pixel_source(face, i, j, S, im_w, im_h);
+  // The reference does not clamp (equi2cube.cpp:47-50); only the exact pole could leave the image.
+  const int row = min(max(d.row, 0), im_h - 1), col = min(max(d.col, 0), im_w - 1);
+  table[o] = row * im_w + col;
+  if (d.sensitive) tie_append(ties, static_cast<unsigned int>(o));
+}
+
+__global__ __launch_bounds__(256) void crop_table_kernel(int im_h, int im_w, Rot3 R, int* __restrict__ table, TieList ties) {
+  const size_t o = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (o >= static_cast<size_t>(im_h / 4) * im_w) return;
+  const int i = static_cast<int>(o / im_w), j = static_cast<int>(o % im_w);
+  const PixelDecision d = rotate_pixel(i + im_h * 3 / 8, j, R, im_w, im_h);               // inverse warping, .cpp:91-96
+  const bool inside = d.row >= 0 && d.col >= 0 && d.row < im_h && d.col < im_w;           // .cpp:100
+  table[o] = inside ? d.row * im_w + d.col : -1;
+  if (d.sensitive) tie_append(ties, static_cast<unsigned int>(o));
+}
+
+__global__ void table_patch_kernel(int* __restrict__ table, const unsigned int* __restrict__ idx,
+                                   const int* __restrict__ val, unsigned int count) {
+  const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < count) table[idx[k]] = val[k];
+}
+
+// 3 source bytes of pixel p as the low 24 bits of one (unaligned) dword load; the last pixel of a frame reads one byte
+// early instead of one byte past the end.  p < 0: outside -> 0.
+__device__ __forceinline__ uint32_t load_pixel(const uint8_t* __restrict__ src, int p, int last_pixel) {
+  if (p < 0) return 0u;
+  uint32_t v;
+  if (p == last_pixel) {
+    if (p == 0) return src[0] | (static_cast<uint32_t>(src[1]) << 8) | (static_cast<uint32_t>(src[2]) << 16);
+    __builtin_memcpy(&v, src + static_cast<size_t>(p) * 3 - 1, 4);
+    return v >> 8;
+  }
+  __builtin_memcpy(&v, src + static_cast<size_t>(p) * 3, 4);
+  return v & 0x00ffffffu;
+}
+
+// out[f][o] = src[f][table[o]] for every frame f of the block's slice of the batch.  PIX = 4: a lane owns 4 consecutive
+// output pixels (one 16-byte table load, 12 output bytes = 3 dword stores); frames are taken two at a time so that eight
+// independent gathers are in flight per lane.
+template <int PIX>
+__global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ table, size_t out_pixels,
+                                                     const uint8_t* __restrict__ src, size_t src_stride, int src_pixels,
+                                                     uint8_t* __restrict__ out, size_t out_stride, int batch,
+                                                     int frames_per_block) {
+  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g * PIX >= out_pixels) return;
+  int p[PIX];
+  if (PIX == 4) {
+    const int4 q = reinterpret_cast<const int4*>(table)[g];
+    p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+  } else {
+    p[0] = table[g];
+  }
+  const int last = src_pixels - 1;
+  const size_t o = g * PIX * 3;
+  const int f0 = blockIdx.y * frames_per_block, f1 = min(batch, f0 + frames_per_block);
+  auto emit = [&](uint8_t* dst, const uint32_t* v) {
+    if (PIX == 4) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(dst + o);     // 12-byte group, 4-byte aligned
+      o32[0] = v[0] | (v[1] << 24);
+      o32[1] = (v[1] >> 8) | (v[2] << 16);
+      o32[2] = (v[2] >> 16) | (v[3] << 8);
+    } else {
+      dst[o] = static_cast<uint8_t>(v[0]); dst[o + 1] = static_cast<uint8_t>(v[0] >> 8); dst[o + 2] = static_cast<uint8_t>(v[0] >> 16);
+    }
+  };
+  int f = f0;
+  for (; f + 1 < f1; f += 2) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    const uint8_t* sb = sa + src_stride;
+    uint32_t va[PIX], vb[PIX];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) { va[k] = load_pixel(sa, p[k], last); vb[k] = load_pixel(sb, p[k], last); }
+    emit(out + static_cast<size_t>(f) * out_stride, va);
+    emit(out + static_cast<size_t>(f + 1) * out_stride, vb);
+  }
+  if (f < f1) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    uint32_t va[PIX];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) va[k] = load_pixel(sa, p[k], last);
+    emit(out + static_cast<size_t>(f) * out_stride, va);
+  }
+}
+
+// ---- key-point maps ---------------------------------------------------------------------------------------------
+// In place on records whose first two floats are pt.x, pt.y.  A record with a sensitive decision is left untouched
+// and listed; the host finishes it from the original coordinates.
+__global__ void rotate_keypoints_kernel(uint8_t* __restrict__ kp, size_t n, size_t stride, Rot3 R, int width,
+                                        int height, TieList ties) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* rec = reinterpret_cast<float*>(kp + i * stride);
+  const PixelDecision d = rotate_keypoint_record(rec[0], rec[1], R, width, height);
+  if (d.sensitive) { tie_append(ties, static_cast<unsigned int>(i)); return; }
+  rec[0] = static_cast<float>(d.col);       // key.pt.x = vec_pixel[1]  (.cpp:120)
+  rec[1] = static_cast<float>(d.row);       // key.pt.y = vec_pixel[0]  (.cpp:121)
+}
+
+__global__ void cube2equi_kernel(uint8_t* __restrict__ kp, size_t n, size_t stride, int S, int im_w, int im_h,
+                                 TieList ties) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* rec = reinterpret_cast<float*>(kp + i * stride);
+  const FloatDecision d = cube2equi_pixel(rec[0], rec[1], S, im_w, im_h);
+  if (d.sensitive) { tie_append(ties, static_cast<unsigned int>(i)); return; }
+  rec[0] = d.x;
+  rec[1] = d.y;
+}
+
+// listed records <-> a compact (x, y) array
+__global__ void records_gather_kernel(const uint8_t* __restrict__ kp, size_t stride, const unsigned int* __restrict__ idx,
+                                      unsigned int count, float2* __restrict__ xy) {
+  const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const float* rec = reinterpret_cast<const float*>(kp + static_cast<size_t>(idx[k]) * stride);
+  xy[k] = make_float2(rec[0], rec[1]);
+}
+__global__ void records_scatter_kernel(uint8_t* __restrict__ kp, size_t stride, const unsigned int* __restrict__ idx,
+                                       unsigned int count, const float2* __restrict__ xy) {
+  const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  float* rec = reinterpret_cast<float*>(kp + static_cast<size_t>(idx[k]) * stride);
+  rec[0] = xy[k].x;
+  rec[1] = xy[k].y;
 }
 
 // eular2rot(Vec3f(0, RAD(pitch), 0)) (spherical_surf.cpp:18-45): float angle, float cos/sin (std::cos(float)),
@@ -101,17 +281,203 @@ int require_device(int device) {
   return SBA_OK;
 }
 
-// Round trip of `bytes` of key-point records through the device around `launch`.
-template <typename Launch>
-int with_device_copy(int device, void* host, size_t bytes, Launch&& launch) {
+// Device-side list + its host read-back.
+struct TieBuffers {
+  DeviceBuffer count, index;
+  TieList list{nullptr, nullptr, 0};
+  int alloc(size_t capacity, hipStream_t stream) {
+    SBA_TRY_HIP(count.alloc(sizeof(unsigned int)));
+    SBA_TRY_HIP(index.alloc(std::max<size_t>(capacity, 1) * sizeof(unsigned int)));
+    SBA_TRY_HIP(hipMemsetAsync(count.ptr, 0, sizeof(unsigned int), stream));
+    list = TieList{count.as<unsigned int>(), index.as<unsigned int>(), static_cast<unsigned int>(capacity)};
+    return SBA_OK;
+  }
+  // synchronises `stream`
+  int read(hipStream_t stream, std::vector<unsigned int>* out) {
+    unsigned int c = 0;
+    SBA_TRY_HIP(hipMemcpyAsync(&c, count.ptr, sizeof(c), hipMemcpyDeviceToHost, stream));
+    SBA_TRY_HIP(hipStreamSynchronize(stream));
+    if (c > list.capacity) return set_error(SBA_ERR_HIP, "internal: tie list overflow (%u > %u)", c, list.capacity);
+    out->resize(c);
+    if (c > 0) {
+      SBA_TRY_HIP(hipMemcpyAsync(out->data(), index.ptr, c * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+      SBA_TRY_HIP(hipStreamSynchronize(stream));
+    }
+    return SBA_OK;
+  }
+};
+
+// ---- table cache ----------------------------------------------------------------------------------------------------
+enum { TABLE_EQUI2CUBE = 0, TABLE_CROP = 1 };
+struct TableKey {
+  int device, kind, param, im_h, im_w;     // param: cube size, or the bit pattern of the float pitch
+  bool operator==(const TableKey& o) const {
+    return device == o.device && kind == o.kind && param == o.param && im_h == o.im_h && im_w == o.im_w;
+  }
+};
+struct Table {
+  TableKey key{};
+  int* dev = nullptr;
+  size_t out_pixels = 0;
+  size_t host_decided = 0;    // outputs finished on the host when the table was built
+};
+std::mutex g_table_mutex;
+std::list<Table> g_tables;          // most recently used first; a handful of geometries per process
+constexpr size_t kMaxTables = 12;
+
+int build_table(const TableKey& key, float pitch_deg, hipStream_t stream, Table* t) {
+  t->key = key;
+  const int S = key.param;
+  t->out_pixels = key.kind == TABLE_EQUI2CUBE ? static_cast<size_t>(S) * 6 * S : static_cast<size_t>(key.im_h / 4) * key.im_w;
+  const size_t padded = (t->out_pixels + 3) / 4 * 4;
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->dev), std::max<size_t>(padded, 4) * sizeof(int)));
+  struct Release { Table* t; bool armed = true; ~Release() { if (armed && t->dev) { (void)hipFree(t->dev); t->dev = nullptr; } } } release{t};
+  SBA_TRY_HIP(hipMemsetAsync(t->dev, 0xff, std::max<size_t>(padded, 4) * sizeof(int), stream));   // padding = -1
+  TieBuffers ties;
+  int rc = ties.alloc(t->out_pixels, stream);
+  if (rc) return rc;
+  const Rot3 R = pitch_rotation(pitch_deg);
+  const unsigned grid = static_cast<unsigned>((t->out_pixels + 255) / 256);
+  if (t->out_pixels > 0) {
+    if (key.kind == TABLE_EQUI2CUBE)
+      hipLaunchKernelGGL(equi2cube_table_kernel, dim3(grid), dim3(256), 0, stream, S, key.im_h, key.im_w, t->dev, ties.list);
+    else
+      hipLaunchKernelGGL(crop_table_kernel, dim3(grid), dim3(256), 0, stream, key.im_h, key.im_w, R, t->dev, ties.list);
+    SBA_TRY_HIP(hipGetLastError());
+  }
+  std::vector<unsigned int> idx;
+  rc = ties.read(stream, &idx);
+  if (rc) return rc;
+  t->host_decided = idx.size();
+  if (!idx.empty()) {
+    // the sensitive decisions, taken by the same function compiled for the host (glibc libm, like the reference)
+    std::vector<int> val(idx.size());
+    for (size_t k = 0; k < idx.size(); ++k) {
+      const unsigned int o = idx[k];
+      if (key.kind == TABLE_EQUI2CUBE) {
+        const int i = static_cast<int>(o / (6u * S)), c = static_cast<int>(o % (6u * S));
+        const PixelDecision d = cube_pixel_source(c / S, i, c % S, S, key.im_w, key.im_h);
+        const int row = std::min(std::max(d.row, 0), key.im_h - 1), col = std::min(std::max(d.col, 0), key.im_w - 1);
+        val[k] = row * key.im_w + col;
+      } else {
+        const int i = static_cast<int>(o / key.im_w), j = static_cast<int>(o % key.im_w);
+        const PixelDecision d = rotate_pixel(i + key.im_h * 3 / 8, j, R, key.im_w, key.im_h);
+        const bool inside = d.row >= 0 && d.col >= 0 && d.row < key.im_h && d.col < key.im_w;
+        val[k] = inside ? d.row * key.im_w + d.col : -1;
+      }
+    }
+    DeviceBuffer val_dev;
+    SBA_TRY_HIP(val_dev.alloc(val.size() * sizeof(int)));
+    SBA_TRY_HIP(hipMemcpyAsync(val_dev.ptr, val.data(), val.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(table_patch_kernel, dim3(static_cast<unsigned>((idx.size() + 255) / 256)), dim3(256), 0, stream,
+                       t->dev, ties.list.index, val_dev.as<int>(), static_cast<unsigned int>(idx.size()));
+    SBA_TRY_HIP(hipGetLastError());
+    SBA_TRY_HIP(hipStreamSynchronize(stream));
+  }
+  release.armed = false;
+  return SBA_OK;
+}
+
+// The table for `key` (built on first use; the build synchronises `stream`).  The returned pointer stays valid until
+// kMaxTables other geometries have been used on top of it.
+int get_table(const TableKey& key, float pitch_deg, hipStream_t stream, Table* out) {
+  std::lock_guard<std::mutex> lock(g_table_mutex);
+  for (auto it = g_tables.begin(); it != g_tables.end(); ++it)
+    if (it->key == key) {
+      g_tables.splice(g_tables.begin(), g_tables, it);
+      *out = g_tables.front();
+      return SBA_OK;
+    }
+  Table t;
+  const int rc = build_table(key, pitch_deg, stream, &t);
+  if (rc) return rc;
+  g_tables.push_front(t);
+  while (g_tables.size() > kMaxTables) {
+    // a table may still be read by a gather enqueued on some stream of its device: drain before freeing
+    (void)hipSetDevice(g_tables.back().key.device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g_tables.back().dev);
+    g_tables.pop_back();
+    (void)hipSetDevice(key.device);
+  }
+  *out = g_tables.front();
+  return SBA_OK;
+}
+
+int launch_gather(const Table& t, const uint8_t* src, int src_pixels, int batch, uint8_t* out, hipStream_t stream) {
+  if (t.out_pixels == 0 || batch <= 0) return SBA_OK;
+  const size_t src_stride = static_cast<size_t>(src_pixels) * 3, out_stride = t.out_pixels * 3;
+  const bool wide = t.out_pixels % 4 == 0;
+  const size_t groups = wide ? t.out_pixels / 4 : t.out_pixels;
+  const unsigned gx = static_cast<unsigned>((groups + 255) / 256);
+  // frames per block: the table entries are loaded once per block and reused; keep >= ~2048 blocks in flight
+  int fpb = 1;
+  while (fpb < 16 && fpb * 2 <= batch && static_cast<size_t>(gx) * ((batch + 2 * fpb - 1) / (2 * fpb)) >= 2048) fpb *= 2;
+  const unsigned gy = static_cast<unsigned>((batch + fpb - 1) / fpb);
+  if (wide)
+    hipLaunchKernelGGL((gather_kernel<4>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride,
+                       src_pixels, out, out_stride, batch, fpb);
+  else
+    hipLaunchKernelGGL((gather_kernel<1>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride,
+                       src_pixels, out, out_stride, batch, fpb);
+  SBA_TRY_HIP(hipGetLastError());
+  return SBA_OK;
+}
+
+int check_image(int im_height, int im_width) {
+  if (im_height <= 0 || im_width <= 0) return set_error(SBA_ERR_INVALID_ARG, "bad image size");
+  if (static_cast<long long>(im_height) * im_width > 0x7fffffffLL / 3)
+    return set_error(SBA_ERR_INVALID_ARG, "image too large for 32-bit pixel indices");
+  return SBA_OK;
+}
+
+// Key-point records on the device, in place: launch, read the list of sensitive records, finish those on the host.
+template <typename Launch, typename HostDecide>
+int keypoints_in_place(hipStream_t stream, uint8_t* kp_dev, size_t n, size_t stride, Launch&& launch, HostDecide&& decide) {
+  if (n == 0) return SBA_OK;
+  if (n > 0xffffffffull) return set_error(SBA_ERR_INVALID_ARG, "too many key-points");
+  TieBuffers ties;
+  int rc = ties.alloc(n, stream);
+  if (rc) return rc;
+  launch(ties.list);
+  SBA_TRY_HIP(hipGetLastError());
+  std::vector<unsigned int> idx;
+  rc = ties.read(stream, &idx);
+  if (rc || idx.empty()) return rc;
+  const unsigned int count = static_cast<unsigned int>(idx.size());
+  const unsigned grid = (count + 255) / 256;
+  DeviceBuffer xy_dev;
+  SBA_TRY_HIP(xy_dev.alloc(count * sizeof(float2)));
+  hipLaunchKernelGGL(records_gather_kernel, dim3(grid), dim3(256), 0, stream, kp_dev, stride, ties.list.index, count, xy_dev.as<float2>());
+  SBA_TRY_HIP(hipGetLastError());
+  std::vector<float2> xy(count);
+  SBA_TRY_HIP(hipMemcpyAsync(xy.data(), xy_dev.ptr, count * sizeof(float2), hipMemcpyDeviceToHost, stream));
+  SBA_TRY_HIP(hipStreamSynchronize(stream));
+  for (float2& q : xy) decide(&q.x, &q.y);
+  SBA_TRY_HIP(hipMemcpyAsync(xy_dev.ptr, xy.data(), count * sizeof(float2), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(records_scatter_kernel, dim3(grid), dim3(256), 0, stream, kp_dev, stride, ties.list.index, count, xy_dev.as<float2>());
+  SBA_TRY_HIP(hipGetLastError());
+  SBA_TRY_HIP(hipStreamSynchronize(stream));     // xy (host) and the scratch buffers go out of scope
+  return SBA_OK;
+}
+
+int check_records(const void* keypoints, size_t n, size_t stride_bytes) {
+  if (n > 0 && !keypoints) return set_error(SBA_ERR_INVALID_ARG, "null key-point array");
+  if (stride_bytes < 8 || stride_bytes % 4 != 0) return set_error(SBA_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 8");
+  return SBA_OK;
+}
+
+// Host arrays: round trip of `bytes` through the device around `work(dev)`.
+template <typename Work>
+int with_device_copy(int device, void* host, size_t bytes, Work&& work) {
   int rc = require_device(device);
   if (rc) return rc;
   if (bytes == 0) return SBA_OK;
   DeviceBuffer dev;
   SBA_TRY_HIP(dev.alloc(bytes));
   SBA_TRY_HIP(hipMemcpy(dev.ptr, host, bytes, hipMemcpyHostToDevice));
-  launch(dev.as<uint8_t>());
-  SBA_TRY_HIP(hipGetLastError());
+  rc = work(dev.as<uint8_t>());
+  if (rc) return rc;
   SBA_TRY_HIP(hipMemcpy(host, dev.ptr, bytes, hipMemcpyDeviceToHost));
   return SBA_OK;
 }
@@ -121,47 +487,152 @@ int with_device_copy(int device, void* host, size_t bytes, Launch&& launch) {
 
 extern "C" {
 
+// ---- key-point maps ---------------------------------------------------------------------------------------------
+int sba_rotate_keypoints_device(int device, void* stream, void* keypoints_dev, size_t n, size_t stride_bytes,
+                                float pitch_deg, int im_width, int im_height) {
+  int rc = sba::check_records(keypoints_dev, n, stride_bytes);
+  if (rc) return rc;
+  if (im_width <= 0 || im_height <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image size");
+  rc = sba::require_device(device);
+  if (rc) return rc;
+  const sba::Rot3 R = sba::pitch_rotation(pitch_deg);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint8_t* kp = static_cast<uint8_t*>(keypoints_dev);
+  return sba::keypoints_in_place(st, kp, n, stride_bytes,
+      [&](const sba::TieList& ties) {
+        hipLaunchKernelGGL(sba::rotate_keypoints_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, kp, n,
+                           stride_bytes, R, im_width, im_height, ties);
+      },
+      [&](float* x, float* y) {
+        const sba::PixelDecision d = sba::rotate_keypoint_record(*x, *y, R, im_width, im_height);
+        *x = static_cast<float>(d.col);
+        *y = static_cast<float>(d.row);
+      });
+}
+
 int sba_rotate_keypoints(int device, void* keypoints, size_t n, size_t stride_bytes, float pitch_deg, int im_width,
                          int im_height) {
-  if (n > 0 && !keypoints) return sba::set_error(SBA_ERR_INVALID_ARG, "null key-point array");
-  if (stride_bytes < 8 || stride_bytes % 4 != 0) return sba::set_error(SBA_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 8");
+  int rc = sba::check_records(keypoints, n, stride_bytes);
+  if (rc) return rc;
   if (im_width <= 0 || im_height <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image size");
-  const sba::Rot3 R = sba::pitch_rotation(pitch_deg);
   return sba::with_device_copy(device, keypoints, n * stride_bytes, [&](uint8_t* dev) {
-    hipLaunchKernelGGL(sba::rotate_keypoints_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr,
-                       dev, n, stride_bytes, R, im_width, im_height);
+    return sba_rotate_keypoints_device(device, nullptr, dev, n, stride_bytes, pitch_deg, im_width, im_height);
   });
+}
+
+int sba_cube2equi_keypoints_device(int device, void* stream, void* keypoints_dev, size_t n, size_t stride_bytes,
+                                   int cube_size, int im_width, int im_height) {
+  int rc = sba::check_records(keypoints_dev, n, stride_bytes);
+  if (rc) return rc;
+  if (im_width <= 0 || im_height <= 0 || cube_size <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image / cube size");
+  rc = sba::require_device(device);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint8_t* kp = static_cast<uint8_t*>(keypoints_dev);
+  return sba::keypoints_in_place(st, kp, n, stride_bytes,
+      [&](const sba::TieList& ties) {
+        hipLaunchKernelGGL(sba::cube2equi_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, kp, n,
+                           stride_bytes, cube_size, im_width, im_height, ties);
+      },
+      [&](float* x, float* y) {
+        const sba::FloatDecision d = sba::cube2equi_pixel(*x, *y, cube_size, im_width, im_height);
+        *x = d.x;
+        *y = d.y;
+      });
 }
 
 int sba_cube2equi_keypoints(int device, void* keypoints, size_t n, size_t stride_bytes, int cube_size, int im_width,
                             int im_height) {
-  if (n > 0 && !keypoints) return sba::set_error(SBA_ERR_INVALID_ARG, "null key-point array");
-  if (stride_bytes < 8 || stride_bytes % 4 != 0) return sba::set_error(SBA_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 8");
+  int rc = sba::check_records(keypoints, n, stride_bytes);
+  if (rc) return rc;
   if (im_width <= 0 || im_height <= 0 || cube_size <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image / cube size");
   return sba::with_device_copy(device, keypoints, n * stride_bytes, [&](uint8_t* dev) {
-    hipLaunchKernelGGL(sba::cube2equi_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, dev,
-                       n, stride_bytes, cube_size, im_width, im_height);
+    return sba_cube2equi_keypoints_device(device, nullptr, dev, n, stride_bytes, cube_size, im_width, im_height);
   });
+}
+
+// ---- image maps ---------------------------------------------------------------------------------------------------
+int sba_crop_rotated_image_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
+                                  float pitch_deg, int batch, void* out_dev) {
+  if (!erp_dev || !out_dev) return sba::set_error(SBA_ERR_INVALID_ARG, "null image pointer");
+  if (im_height < 4 || batch <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image size / batch");
+  int rc = sba::check_image(im_height, im_width);
+  if (rc) return rc;
+  rc = sba::require_device(device);
+  if (rc) return rc;
+  int pitch_bits;
+  std::memcpy(&pitch_bits, &pitch_deg, sizeof(pitch_bits));
+  sba::Table t;
+  rc = sba::get_table(sba::TableKey{device, sba::TABLE_CROP, pitch_bits, im_height, im_width}, pitch_deg,
+                      static_cast<hipStream_t>(stream), &t);
+  if (rc) return rc;
+  return sba::launch_gather(t, static_cast<const uint8_t*>(erp_dev), im_height * im_width, batch,
+                            static_cast<uint8_t*>(out_dev), static_cast<hipStream_t>(stream));
 }
 
 int sba_crop_rotated_image(int device, const uint8_t* erp, int im_height, int im_width, float pitch_deg,
                            uint8_t* out) {
   if (!erp || !out) return sba::set_error(SBA_ERR_INVALID_ARG, "null image pointer");
-  if (im_height < 4 || im_width <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image size");
-  int rc = sba::require_device(device);
+  if (im_height < 4) return sba::set_error(SBA_ERR_INVALID_ARG, "bad image size");
+  int rc = sba::check_image(im_height, im_width);
+  if (rc) return rc;
+  rc = sba::require_device(device);
   if (rc) return rc;
   const size_t in_bytes = static_cast<size_t>(im_height) * im_width * 3;
-  const size_t px = static_cast<size_t>(im_height / 4) * im_width;
+  const size_t out_bytes = static_cast<size_t>(im_height / 4) * im_width * 3;
   sba::DeviceBuffer in_dev, out_dev;
   SBA_TRY_HIP(in_dev.alloc(in_bytes));
-  SBA_TRY_HIP(out_dev.alloc(px * 3));
+  SBA_TRY_HIP(out_dev.alloc(out_bytes));
   SBA_TRY_HIP(hipMemcpy(in_dev.ptr, erp, in_bytes, hipMemcpyHostToDevice));
-  const sba::Rot3 R = sba::pitch_rotation(pitch_deg);
-  hipLaunchKernelGGL(sba::crop_rotated_kernel, dim3(static_cast<unsigned>((px + 255) / 256)), dim3(256), 0, nullptr,
-                     in_dev.as<uint8_t>(), im_height, im_width, R, out_dev.as<uint8_t>());
-  SBA_TRY_HIP(hipGetLastError());
-  SBA_TRY_HIP(hipMemcpy(out, out_dev.ptr, px * 3, hipMemcpyDeviceToHost));
+  rc = sba_crop_rotated_image_device(device, nullptr, in_dev.ptr, im_height, im_width, pitch_deg, 1, out_dev.ptr);
+  if (rc) return rc;
+  SBA_TRY_HIP(hipMemcpy(out, out_dev.ptr, out_bytes, hipMemcpyDeviceToHost));   // synchronises with the null stream
   return SBA_OK;
+}
+
+int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
+                         int cube_size, int batch, void* out_dev) {
+  if (!erp_dev || !out_dev) return sba::set_error(SBA_ERR_INVALID_ARG, "null image pointer");
+  if (cube_size <= 0 || batch <= 0 || cube_size > 16384) return sba::set_error(SBA_ERR_INVALID_ARG, "bad cube size / batch");
+  int rc = sba::check_image(im_height, im_width);
+  if (rc) return rc;
+  rc = sba::require_device(device);
+  if (rc) return rc;
+  sba::Table t;
+  rc = sba::get_table(sba::TableKey{device, sba::TABLE_EQUI2CUBE, cube_size, im_height, im_width}, 0.0f,
+                      static_cast<hipStream_t>(stream), &t);
+  if (rc) return rc;
+  return sba::launch_gather(t, static_cast<const uint8_t*>(erp_dev), im_height * im_width, batch,
+                            static_cast<uint8_t*>(out_dev), static_cast<hipStream_t>(stream));
+}
+
+int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, int cube_size,
+                  uint8_t* out) {
+  if (!erp || !out) return sba::set_error(SBA_ERR_INVALID_ARG, "null image pointer");
+  if (cube_size <= 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad cube size");
+  int rc = sba::check_image(im_height, im_width);
+  if (rc) return rc;
+  rc = sba::require_device(device);
+  if (rc) return rc;
+  const size_t in_bytes = static_cast<size_t>(im_height) * im_width * 3;
+  const size_t out_bytes = static_cast<size_t>(cube_size) * 6 * cube_size * 3;
+  sba::DeviceBuffer in_dev, out_dev;
+  SBA_TRY_HIP(in_dev.alloc(in_bytes));
+  SBA_TRY_HIP(out_dev.alloc(out_bytes));
+  SBA_TRY_HIP(hipMemcpy(in_dev.ptr, erp, in_bytes, hipMemcpyHostToDevice));
+  rc = sba_equi2cube_device(device, nullptr, in_dev.ptr, im_height, im_width, cube_size, 1, out_dev.ptr);
+  if (rc) return rc;
+  SBA_TRY_HIP(hipMemcpy(out, out_dev.ptr, out_bytes, hipMemcpyDeviceToHost));   // synchronises with the null stream
+  return SBA_OK;
+}
+
+// How many outputs of the cached table for this geometry were decided on the host (diagnostics / tests); -1 if the
+// table has not been built.  kind: 0 = equi2cube (param = cube size), 1 = crop (param = bit pattern of the float pitch).
+long sba_map_table_host_decided(int device, int kind, int param, int im_height, int im_width) {
+  std::lock_guard<std::mutex> lock(sba::g_table_mutex);
+  for (const sba::Table& t : sba::g_tables)
+    if (t.key == sba::TableKey{device, kind, param, im_height, im_width}) return static_cast<long>(t.host_decided);
+  return -1;
 }
 
 }  // extern "C"

@@ -59,7 +59,9 @@ struct sba_problem {
   void* peer_opened[sba::kMaxPeers] = {nullptr};
   bool peer_ready = false;
   unsigned long long xseq = 0;
-  unsigned long long peer_spin_limit = 20000000ull;   // bounded wait (tens of seconds) before SBA_ERR_COMM
+  double peer_timeout_s = 20.0;           // longest wait for a peer's slot before SBA_ERR_COMM (SBA_PEER_TIMEOUT_S)
+  int wall_clock_khz = 100000;            // rate of the device's constant wall clock (hipDeviceAttributeWallClockRate)
+  unsigned long long* peer_sticky = nullptr;   // device word: some exchange timed out (never cleared while connected)
 
   sba_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;

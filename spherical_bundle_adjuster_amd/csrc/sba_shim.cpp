@@ -244,15 +244,15 @@ int enqueue_sweep(sba_problem* p, int mode, int depth_mode, const sba::SweepPara
     double* host = p->publish ? p->pack_host_dev : nullptr;
     if (!fused)
       SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, host, p->seq, &p->peers, ++p->xseq,
-                                       p->peer_spin_limit, p->stream));
+                                       p->stream));
     else
       SBA_HIP_TRY(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev, host, p->seq,
-                                            p->peer_spin_limit, p->stream));
+                                            p->stream));
     return SBA_OK;
   }
   if (!fused)
     SBA_HIP_TRY(sba::launch_finalize(p->partials, grid, p->pack_dev, to_host ? p->pack_host_dev : nullptr, p->seq,
-                                     nullptr, 0, 0, p->stream));
+                                     nullptr, 0, p->stream));
   if (collective) return allreduce_pack(p);
   return SBA_OK;
 }
@@ -350,6 +350,11 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   hipDeviceProp_t prop;
   SBA_HIP_TRY(hipGetDeviceProperties(&prop, device));
   p->num_cus = prop.multiProcessorCount;
+  int wall_khz = 0;
+  if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && wall_khz > 0)
+    p->wall_clock_khz = wall_khz;
+  else
+    (void)hipGetLastError();
   if (const char* env = std::getenv("SBA_BLOCKS_PER_CU")) {
     const int v = std::atoi(env);
     if (v >= 1 && v <= 8) p->blocks_per_cu_cap = v;
@@ -401,6 +406,7 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->partials) (void)hipFree(p->partials);
   if (p->pack_dev) (void)hipFree(p->pack_dev);
   if (p->ticket) (void)hipFree(p->ticket);
+  if (p->peer_sticky) (void)hipFree(p->peer_sticky);
   if (p->epi_scratch) (void)hipFree(p->epi_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -719,38 +725,6 @@ int sba_keypoints_to_sphere(int device, const void* keypoints, size_t n, size_t 
   SBA_HIP_TRY(sba::launch_keypoints_to_sphere(kp_dev.as<uint8_t>(), n, stride_bytes, im_width, im_height,
                                               out_dev.as<double>(), nullptr));
   SBA_HIP_TRY(hipMemcpy(out_xyz, out_dev.ptr, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  return SBA_OK;
-}
-
-int sba_equi2cube_device(int device, void* stream, const void* erp_dev, int im_height, int im_width,
-                         int cube_size, int batch, void* out_dev) {
-  if (!erp_dev || !out_dev) return fail(SBA_ERR_INVALID_ARG, "null image pointer");
-  if (im_height <= 0 || im_width <= 0 || cube_size <= 0 || batch <= 0)
-    return fail(SBA_ERR_INVALID_ARG, "bad image / cube size");
-  if (static_cast<long long>(im_height) * im_width > 0x7fffffffLL / 3)
-    return fail(SBA_ERR_INVALID_ARG, "image too large for 32-bit pixel indices");
-  int rc = require_device(device);
-  if (rc) return rc;
-  SBA_HIP_TRY(sba::launch_equi2cube(static_cast<const uint8_t*>(erp_dev), im_height, im_width, cube_size,
-                                    batch, static_cast<uint8_t*>(out_dev), static_cast<hipStream_t>(stream)));
-  return SBA_OK;
-}
-
-int sba_equi2cube(int device, const uint8_t* erp, int im_height, int im_width, int cube_size,
-                  uint8_t* out) {
-  if (!erp || !out) return fail(SBA_ERR_INVALID_ARG, "null image pointer");
-  if (im_height <= 0 || im_width <= 0 || cube_size <= 0) return fail(SBA_ERR_INVALID_ARG, "bad image / cube size");
-  int rc = require_device(device);
-  if (rc) return rc;
-  const size_t in_bytes = static_cast<size_t>(im_height) * im_width * 3;
-  const size_t out_bytes = static_cast<size_t>(cube_size) * 6 * cube_size * 3;
-  sba::DeviceBuffer in_dev, out_dev;
-  SBA_HIP_TRY(in_dev.alloc(in_bytes));
-  SBA_HIP_TRY(out_dev.alloc(out_bytes));
-  SBA_HIP_TRY(hipMemcpy(in_dev.ptr, erp, in_bytes, hipMemcpyHostToDevice));
-  rc = sba_equi2cube_device(device, nullptr, in_dev.ptr, im_height, im_width, cube_size, 1, out_dev.ptr);
-  if (rc) return rc;
-  SBA_HIP_TRY(hipMemcpy(out, out_dev.ptr, out_bytes, hipMemcpyDeviceToHost));   // synchronises with the null stream
   return SBA_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -48,8 +49,7 @@ int allreduce_pack(sba_problem* p) {
     p->published = p->publish;
     if (p->publish) ++p->seq;
     SBA_TRY_HIP(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev,
-                                          p->publish ? p->pack_host_dev : nullptr, p->seq, p->peer_spin_limit,
-                                          p->stream));
+                                          p->publish ? p->pack_host_dev : nullptr, p->seq, p->stream));
     return SBA_OK;
   }
   if (p->comm) {
@@ -73,15 +73,15 @@ int allreduce_pack(sba_problem* p) {
 
 // SUM all-reduce of `count` doubles at `dev` (count a multiple of 24) over the attached transport, in stream order.
 // Over the peer transport the buffer travels as count / 24 back-to-back exchanges of the 24-double inbox slots; the
-// last one publishes to the host so that a timeout shows in word 25 of the host pack (checked by the caller).
+// last one publishes to the host, and since every exchange reports the STICKY device-side timeout word, a timeout in any
+// of them shows in word 25 of the host pack (checked by the caller).
 int allreduce_buffer(sba_problem* p, double* dev, size_t count) {
   if (p->peer_ready) {
     if (count % SBA_PACK_SIZE != 0) return sba::set_error(SBA_ERR_INVALID_ARG, "peer all-reduce needs a multiple of 24 doubles");
     for (size_t off = 0; off < count; off += SBA_PACK_SIZE) {
       const bool last = off + SBA_PACK_SIZE >= count;
       SBA_TRY_HIP(sba::launch_peer_exchange(dev + off, p->peers, ++p->xseq, dev + off,
-                                            last ? p->pack_host_dev : nullptr, last ? ++p->seq : 0,
-                                            p->peer_spin_limit, p->stream));
+                                            last ? p->pack_host_dev : nullptr, last ? ++p->seq : 0, p->stream));
     }
     return SBA_OK;
   }
@@ -139,6 +139,24 @@ int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char 
   return SBA_OK;
 }
 
+int sba_rccl_available(void) {
+  Rccl& r = rccl();
+  if (!r.ok) { (void)sba::set_error(SBA_ERR_COMM, "%s", r.why.c_str()); return 0; }
+  return 1;
+}
+
+int sba_problem_comm_destroy(sba_problem* p) {
+  if (!p) return SBA_OK;
+  if (p->comm) {
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    Rccl& r = rccl();
+    if (r.ok) r.CommDestroy(p->comm);
+    p->comm = nullptr;
+  }
+  return SBA_OK;
+}
+
 // ---- direct peer exchange ---------------------------------------------------------------------------------------
 int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SBA_PEER_HANDLE_BYTES]) {
   if (!p || !handle) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
@@ -159,6 +177,11 @@ int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SB
   }
   p->inbox = static_cast<double*>(mem);
   SBA_TRY_HIP(hipMemset(p->inbox, 0, bytes));
+  if (!p->peer_sticky) SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&p->peer_sticky), 64));
+  SBA_TRY_HIP(hipMemset(p->peer_sticky, 0, 64));
+  if (const char* env = std::getenv("SBA_PEER_TIMEOUT_S")) { const double v = std::atof(env); if (v > 0.0) p->peer_timeout_s = v; }
+  p->peers.timeout_ticks = static_cast<unsigned long long>(p->peer_timeout_s * 1e3 * p->wall_clock_khz);
+  p->peers.sticky = p->peer_sticky;
   SBA_TRY_HIP(hipDeviceSynchronize());
   hipIpcMemHandle_t h;
   const hipError_t e = hipIpcGetMemHandle(&h, p->inbox);
@@ -219,8 +242,8 @@ int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok) {
   if (!p->peer_ready) return sba::set_error(SBA_ERR_INVALID_ARG, "peer exchange is not connected");
   SBA_TRY_HIP(hipSetDevice(p->device));
   const int n = p->peers.nranks;
-  const unsigned long long limit = p->peer_spin_limit;
-  p->peer_spin_limit = 3000000ull;   // a few seconds at most per round in the self-test
+  const unsigned long long limit = p->peers.timeout_ticks;
+  p->peers.timeout_ticks = static_cast<unsigned long long>(3.0 * 1e3 * p->wall_clock_khz);   // 3 s per round in the self-test
   int good = 1;
   for (int k = 0; k < rounds && good; ++k) {
     double v[32];
@@ -229,7 +252,7 @@ int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok) {
     ++p->seq;
     p->published = true;
     SBA_TRY_HIP(sba::launch_peer_exchange(p->pack_dev, p->peers, ++p->xseq, p->pack_dev, p->pack_host_dev, p->seq,
-                                          p->peer_spin_limit, p->stream));
+                                          p->stream));
     double got[24];
     const int rc = fetch_pack_raw(p, got);
     if (rc != SBA_OK) { good = 0; break; }
@@ -237,7 +260,7 @@ int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok) {
     for (int i = 0; i < 24; ++i)
       if (got[i] != want) good = 0;
   }
-  p->peer_spin_limit = limit;
+  p->peers.timeout_ticks = limit;
   *ok = good;
   return SBA_OK;
 }

@@ -26,17 +26,24 @@ void spherical_bundle_adjuster::set_omp(int n) {
 }
 
 void spherical_bundle_adjuster::do_bundle_adjustment(const cv::Mat& im_left, const cv::Mat& im_right) {
-  if (!matcher) {
-    std::cerr << "spherical_bundle_adjuster: no matcher installed (SURF/FLANN matching is outside the "
-                 "accelerated path; call set_matcher() with spherical_surf::do_all or use "
-                 "do_bundle_adjustment_from_matches())" << std::endl;
-    return;
-  }
   std::vector<cv::KeyPoint> left_key, right_key;
   int match_size = 0, total_key_num = 0;
   cv::Mat match_output;
   std::cout << "Do feature finding and matching" << std::endl;                         // .cpp:262
-  matcher(im_left, im_right, left_key, right_key, match_size, match_output, total_key_num);
+  if (matcher) {
+    matcher(im_left, im_right, left_key, right_key, match_size, match_output, total_key_num);
+  } else {
+#ifdef SBA_WITH_OPENCV
+    spherical_surf fm;                                                                  // .cpp:264-266, verbatim
+    fm.set_omp(this->num_proc);
+    fm.do_all(im_left, im_right, left_key, right_key, match_size, match_output, total_key_num);
+#else
+    std::cerr << "spherical_bundle_adjuster: built without OpenCV, so the reference's default matcher "
+                 "(spherical_surf, SURF/FLANN) is not available: call set_matcher() or use "
+                 "do_bundle_adjustment_from_matches()" << std::endl;
+    return;
+#endif
+  }
   const int rc = do_bundle_adjustment_from_matches(left_key, right_key, match_size, im_left.cols, im_left.rows);
   if (rc != SBA_OK) std::cerr << "spherical_bundle_adjuster: " << sba_last_error() << std::endl;
 }

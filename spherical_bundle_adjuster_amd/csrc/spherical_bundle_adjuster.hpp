@@ -3,15 +3,29 @@
 // so the call sequence of main/main.cpp:29-32 compiles unchanged.  The Ceres-backed private
 // `solve_problem` is replaced by calls into the C-ABI (include/sba_hip.h); nothing here touches Ceres.
 //
-// Out of scope on this path: SURF/FLANN matching.  The reference hard-wires
-// `spherical_surf fm; fm.do_all(...)` (spherical_bundle_adjuster.cpp:264-266); here the matcher is a
-// pluggable callable with the same `do_all` signature, and `do_bundle_adjustment_from_matches` enters
-// right after it, with the matched key-points the reference's matchers return.
+// Out of scope on this path: SURF/FLANN matching, which stays in OpenCV on the host.
+//   * With OpenCV (-DSBA_WITH_OPENCV, the reference tree on the include path): this header pulls in the reference's
+//     own "spherical_surf.hpp" like the header it replaces does (reference spherical_bundle_adjuster.hpp:3), and
+//     do_bundle_adjustment() default-constructs the matcher exactly as the reference does
+//     (`spherical_surf fm; fm.set_omp(num_proc); fm.do_all(...)`, spherical_bundle_adjuster.cpp:264-266) --
+//     main/main.cpp:29-32 compiles AND runs unchanged.
+//   * Without OpenCV (this image): layout-compatible stand-in types (sba_types.hpp); a matcher can be supplied as a
+//     callable with the same `do_all` signature (set_matcher), and `do_bundle_adjustment_from_matches` enters right
+//     after the matcher, with the matched key-points the reference's matchers return.
 #pragma once
 #include <array>
 #include <functional>
 #include <string>
 #include <vector>
+
+#ifdef SBA_WITH_OPENCV
+// what the replaced header includes (reference spherical_bundle_adjuster.hpp:3-13), minus Ceres
+#include "spherical_surf.hpp"
+#include "debug_print.h"
+#include <fstream>
+#include <sstream>
+#include <omp.h>
+#endif
 
 #include "../../include/sba_hip.h"
 #include "sba_types.hpp"
@@ -34,6 +48,7 @@ class spherical_bundle_adjuster {
   void do_bundle_adjustment(const cv::Mat& im_left, const cv::Mat& im_right);
 
   // ---- additions of this build (not in the reference) ------------------------------------------------
+  // Replace the matcher (default with OpenCV: the reference's spherical_surf; without: none).
   void set_matcher(matcher_fn fn) { matcher = std::move(fn); }
   void set_device(int hip_device) { device = hip_device; }
   void set_log_path(const std::string& path) { log_path = path; }   // default "log.txt" (.cpp:349)

@@ -10,9 +10,13 @@ Transports for that exchange (``attach(..., transport=...)``):
                 shipped between ranks with ``torch.distributed``.
   * "hook"   -- ``torch.distributed.all_reduce`` on a tensor aliasing the shim's device pack (needs the problem to
                 launch on torch's current stream).
-  * "auto"   -- "peer" if its set-up and an 8-round self-test succeed on EVERY rank, else "rccl", else "hook".
+  * "auto"   -- "rccl" (the collective BASELINE's north star names) if every rank can load RCCL and joins the
+                communicator, else "hook".  "peer" is opt-in (``transport="peer"`` / ``SBA_TRANSPORT=peer``): its stores
+                into another DEVICE's IPC-mapped inbox have so far only run between processes on one GPU, so it is not
+                a default until it has one cross-device run behind it.
 ``torch.distributed`` is host plumbing here (shipping handles / ids, agreeing on the fallback), never the data path
-of "peer" and "rccl".
+of "peer" and "rccl".  Every rank issues the same sequence of control collectives whatever fails locally, and all ranks
+end on the same transport.
 """
 from __future__ import annotations
 
@@ -73,6 +77,14 @@ def _try_peer(problem: api.Problem, torch, dist) -> bool:
 
 def _try_rccl(problem: api.Problem, torch, dist) -> bool:
     world, rank = dist.get_world_size(), dist.get_rank()
+    # ncclCommInitRank is itself a collective: a rank that cannot even load librccl would leave the others blocked
+    # inside it.  So: agree that everybody CAN call it before anybody does.
+    try:
+        can = bool(api.rccl_available())
+    except Exception:
+        can = False
+    if not _all_agree(torch, dist, can):
+        return False
     uid, ok = bytes(128), 1
     if rank == 0:
         try:
@@ -84,15 +96,27 @@ def _try_rccl(problem: api.Problem, torch, dist) -> bool:
     vals = t.cpu().tolist()
     if vals[0] != 1:
         return False
-    problem.comm_init_rank(world, rank, bytes(vals[1:]))
-    return True
+    joined = True
+    try:
+        problem.comm_init_rank(world, rank, bytes(vals[1:]))
+    except api.SbaError:
+        joined = False
+    # ... and agree afterwards: if any rank came back with an error, every rank drops its communicator and all fall
+    # back together instead of some all-reducing over RCCL and others not.
+    if _all_agree(torch, dist, joined):
+        return True
+    try:
+        problem.comm_destroy()
+    except api.SbaError:
+        pass
+    return False
 
 
 def attach(problem: api.Problem, transport: str = "auto", force: bool = False, prefer_native: bool | None = None) -> str:
     """Install the per-sweep exchange on `problem` for the current torch.distributed world.
     Returns the transport used: "none" (world size 1, unless `force`), "xgmi-peer", "rccl-native" or "torch-hook".
-    `transport`: "auto" | "peer" | "rccl" | "hook" (env SBA_TRANSPORT overrides "auto").  The hook transport
-    requires the problem to have been created on torch's current stream."""
+    `transport`: "auto" (rccl, else hook) | "peer" | "rccl" | "hook" (env SBA_TRANSPORT overrides "auto").  The hook
+    transport requires the problem to have been created on torch's current stream."""
     import torch
     import torch.distributed as dist
 
@@ -102,16 +126,15 @@ def attach(problem: api.Problem, transport: str = "auto", force: bool = False, p
         transport = os.environ.get("SBA_TRANSPORT", "auto")
     if dist.get_world_size() == 1 and not force:
         return "none"
-    if transport in ("auto", "peer"):
+    if transport == "peer":
         if _try_peer(problem, torch, dist):
             return "xgmi-peer"
-        if transport == "peer":
-            raise RuntimeError("direct peer exchange could not be set up on every rank")
+        raise RuntimeError("direct peer exchange could not be set up on every rank")
     if transport in ("auto", "rccl"):
         if _try_rccl(problem, torch, dist):
             return "rccl-native"
         if transport == "rccl":
-            raise RuntimeError("RCCL unique id could not be created")
+            raise RuntimeError("RCCL communicator could not be created on every rank")
     return _install_hook(problem, torch, dist)
 
 

@@ -1,0 +1,1 @@
+#include "opencv2/core.hpp"  // fake, see opencv2/core.hpp

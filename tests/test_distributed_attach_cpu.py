@@ -1,6 +1,6 @@
 """CPU: the transport agreement of distributed.attach() with a 2-rank gloo group and a MOCK problem.  Every rank must
 issue the same sequence of control collectives whatever fails locally (a mismatch would deadlock a multi-GPU job), and
-all ranks must end on the same transport: peer -> rccl -> hook."""
+all ranks must end on the same transport: auto = rccl -> hook; peer only on request."""
 import os
 import socket
 import sys
@@ -10,14 +10,19 @@ import pytest
 from helpers import ROOT
 
 SCENARIOS = {
-    # name: (failure injected on which rank / where, expected transport on every rank)
-    "all_ok": (None, "xgmi-peer"),
-    "export_fails_rank1": ((1, "export"), "rccl-native"),
-    "connect_fails_rank0": ((0, "connect"), "rccl-native"),
-    "selftest_false_rank1": ((1, "selftest"), "rccl-native"),
-    "selftest_raises_rank0": ((0, "selftest_raise"), "rccl-native"),
-    "peer_and_uid_fail": ((0, "export+uid"), "torch-hook"),
-    "forced_rccl": (None, "rccl-native"),
+    # name: (transport asked for, failure injected on which rank / where, expected transport on every rank or "RAISES")
+    "auto_all_ok": ("auto", None, "rccl-native"),
+    "auto_rccl_missing_rank1": ("auto", (1, "norccl"), "torch-hook"),        # nobody may enter ncclCommInitRank
+    "auto_uid_fails": ("auto", (0, "uid"), "torch-hook"),
+    "auto_comm_init_fails_rank1": ("auto", (1, "comm_init"), "torch-hook"),  # rank 0 joined: it must drop its communicator
+    "auto_comm_init_fails_rank0": ("auto", (0, "comm_init"), "torch-hook"),
+    "forced_rccl": ("rccl", None, "rccl-native"),
+    "forced_rccl_comm_init_fails_rank1": ("rccl", (1, "comm_init"), "RAISES"),
+    "peer_all_ok": ("peer", None, "xgmi-peer"),
+    "peer_export_fails_rank1": ("peer", (1, "export"), "RAISES"),
+    "peer_connect_fails_rank0": ("peer", (0, "connect"), "RAISES"),
+    "peer_selftest_false_rank1": ("peer", (1, "selftest"), "RAISES"),
+    "peer_selftest_raises_rank0": ("peer", (0, "selftest_raise"), "RAISES"),
 }
 
 
@@ -27,7 +32,7 @@ def _worker(rank, world, port, scenario, q):
     import torch.distributed as dist
     from spherical_bundle_adjuster_amd import api, distributed
 
-    fail, _ = SCENARIOS[scenario]
+    asked, fail, _ = SCENARIOS[scenario]
     where = fail[1] if fail and fail[0] == rank else ""
 
     class MockProblem:
@@ -58,6 +63,11 @@ def _worker(rank, world, port, scenario, q):
         def comm_init_rank(self, nranks, rank_, uid):
             self.calls.append("comm_init")
             assert uid == bytes(range(128))
+            if where == "comm_init":
+                raise api.SbaError(-5, "injected")
+
+        def comm_destroy(self):
+            self.calls.append("comm_destroy")
 
     def fake_uid():
         if "uid" in where:
@@ -65,11 +75,15 @@ def _worker(rank, world, port, scenario, q):
         return bytes(range(128))
 
     api.comm_unique_id = fake_uid
+    api.rccl_available = lambda: where != "norccl"
     distributed._install_hook = lambda problem, torch, dist_: (problem.calls.append("hook") or "torch-hook")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = MockProblem()
-        used = distributed.attach(p, transport="rccl" if scenario == "forced_rccl" else "auto")
+        try:
+            used = distributed.attach(p, transport=asked)
+        except RuntimeError:
+            used = "RAISES"
         q.put((rank, used, p.calls))
     except Exception:
         import traceback
@@ -90,11 +104,17 @@ def test_attach_agreement(scenario):
     [p.start() for p in procs]
     res = sorted([q.get(timeout=120) for _ in procs])        # a deadlock shows up as a timeout here
     [p.join(30) for p in procs]
-    expected = SCENARIOS[scenario][1]
+    expected = SCENARIOS[scenario][2]
     for rank, used, calls in res:
         assert used == expected, calls
-        if expected != "xgmi-peer" and scenario != "forced_rccl":
+        if scenario.startswith("peer") and expected == "RAISES":
             assert calls.count("disable") == 1                 # every rank tears its peer state down
         if expected == "xgmi-peer":
             assert calls == ["export", "connect", "selftest"]
+        if "rccl_missing" in scenario or "uid_fails" in scenario:
+            assert "comm_init" not in calls                    # nobody entered the (collective) communicator set-up
+        if "comm_init_fails" in scenario:
+            assert calls.count("comm_init") == 1 and calls.count("comm_destroy") == 1   # joined ranks drop theirs too
+        if expected == "torch-hook":
+            assert calls[-1] == "hook"
     assert res[0][1] == res[1][1]

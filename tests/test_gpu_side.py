@@ -4,6 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from spherical_bundle_adjuster_amd import _cabi as cabi
 from spherical_bundle_adjuster_amd import api, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +57,8 @@ def test_upload_keypoints_fused(oracle, store):
             p.upload_keypoints(kl, kr, 0, H)
 
 
-@pytest.mark.parametrize("H,W,S", [(64, 128, 16), (480, 960, 150), (1920, 3840, 600), (100, 200, 33)])
+@pytest.mark.parametrize("H,W,S", [(64, 128, 16), (480, 960, 150), (1920, 3840, 600), (100, 200, 33), (1080, 2160, 512),
+                                   (1000, 2000, 250), (960, 1920, 300)])
 def test_equi2cube_bit_exact(oracle, H, W, S):
     """Byte-exact against the oracle (integer index work): every output pixel identical."""
     rng = np.random.default_rng(H + S)
@@ -130,43 +132,89 @@ def test_set_depths(oracle):
         assert np.abs(got2.H - ref2.H).max() <= 1e-12 * np.abs(ref2.H).max()
 
 
+def _all_band_pixels(H, W):
+    rows = np.arange(H // 4)
+    kp = np.zeros((len(rows) * W, 7), dtype=np.float32)
+    rr, cc = np.meshgrid(rows, np.arange(W), indexing="ij")
+    kp[:, 0], kp[:, 1] = cc.ravel(), rr.ravel()
+    return kp
+
+
+# The bands of spherical_surf::do_all are +45, -45 and -90 (spherical_surf.cpp:137-153, 181-193; the 0 band never goes
+# through rotate_pixel); 0, 30 and 90 ride along because they are the hard cases: at pitch 0 EVERY pixel sits exactly on
+# an integer boundary of `height * acos(..) / M_PI`, at +-90 whole lines do.
+@pytest.mark.parametrize("H,W", [(1920, 3840), (480, 960), (1080, 2160), (1000, 2000)])
+def test_rotate_keypoints_and_crop_bit_exact_every_pitch(oracle, H, W):
+    """Integer pixel maps (rotate_keypoint, crop_rotated_image: spherical_surf.cpp:48-123): ZERO differing results against
+    the oracle over every pixel of the band, for every pitch -- decisions within 1e-6 pixel of an integer are taken on the
+    host with the reference's own C library (csrc/sba_maps.hip)."""
+    lib = cabi.load_library()
+    allkp = _all_band_pixels(H, W)
+    rng = np.random.default_rng(H)
+    im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    pitches = (45.0, -45.0, -90.0, 0.0, 30.0, 90.0) if H <= 1080 else (45.0, -45.0, -90.0)
+    for pitch in pitches:
+        got = api.rotate_keypoints(allkp, pitch, W, H)
+        ref = oracle.rotate_keypoints(allkp, pitch, W, H)
+        assert np.array_equal(got[:, 2:], allkp[:, 2:])
+        bad = (got[:, :2] != ref[:, :2]).any(axis=1)
+        assert not bad.any(), f"pitch {pitch}: {int(bad.sum())} of {len(allkp)} key-points differ"
+        g2 = api.crop_rotated_image(im, pitch)
+        r2 = oracle.crop_rotated_image(im, pitch)
+        assert np.array_equal(g2, r2), f"pitch {pitch}: {int((g2 != r2).any(axis=2).sum())} pixels differ"
+        bits = int(np.float32(pitch).view(np.int32))
+        decided = lib.sba_map_table_host_decided(0, 1, bits, H, W)
+        assert decided >= 0                                   # the table exists (and is reused by the next call)
+        if pitch in (45.0, -45.0, 30.0):
+            assert decided <= 1e-3 * (H // 4) * W             # the host finishes a sliver, the device the rest
+        if pitch == 0.0:
+            assert decided == (H // 4) * W                    # every pixel is an exact tie: all decided by the host
+
+
 def test_matcher_coordinate_maps(oracle):
-    """rotate_keypoint / cube2equi_pixel / crop_rotated_image (spherical_surf.cpp:76-123, equi2cube_surf.cpp:19-76):
-    integer pixel results identical to the oracle, float ones to float rounding."""
+    """rotate_keypoint on real-valued key-points, cube2equi_pixel (equi2cube_surf.cpp:19-76; float32 results, compared
+    bit for bit), device-resident variants, batched crop."""
+    torch = pytest.importorskip("torch")
+    lib = cabi.load_library()
     rng = np.random.default_rng(21)
     H, W, S, n = 1920, 3840, 600, 50001
     kp = np.zeros((n, 7), dtype=np.float32)
     kp[:, 0] = rng.uniform(0, W - 1, n); kp[:, 1] = rng.uniform(0, H // 4 - 1, n)
     kp[:, 2:] = rng.standard_normal((n, 5))                       # size/angle/response/octave/class_id ride along untouched
-    # The bands of spherical_surf::do_all are +45, -45 and -90 (the 0 band only gets the offset added, .cpp:181-184).
-    # +-45: every integer band pixel maps identically.  -90: inputs on column 3W/4 or the equator row land EXACTLY on integer pixel
-    # boundaries (e.g. 2651.0 vs 2650.99..), where the truncation follows the last bit of sin/cos/acos/atan2 -- the
-    # reference's own value there depends on its libm build; those ties (0.008 % of the band) may differ by one pixel.
-    rows = np.arange(H // 4)
-    allkp = np.zeros((len(rows) * W, 7), dtype=np.float32)
-    rr, cc = np.meshgrid(rows, np.arange(W), indexing="ij")
-    allkp[:, 0], allkp[:, 1] = cc.ravel(), rr.ravel()
-    for pitch, allowed in ((45.0, 0.0), (-45.0, 0.0), (-90.0, 2e-4)):
-        for pts in (kp, allkp):
-            got = api.rotate_keypoints(pts, pitch, W, H)
-            ref = oracle.rotate_keypoints(pts, pitch, W, H)
-            assert np.array_equal(got[:, 2:], pts[:, 2:])
-            bad = (got[:, :2] != ref[:, :2]).any(axis=1)
-            assert bad.mean() <= allowed, f"pitch {pitch}: {int(bad.sum())} of {len(pts)} key-points differ"
-            assert np.abs(got[:, :2] - ref[:, :2]).max() <= 1.0
+    stream = torch.cuda.current_stream().cuda_stream
+    for pitch in (45.0, -45.0, -90.0):
+        got = api.rotate_keypoints(kp, pitch, W, H)
+        ref = oracle.rotate_keypoints(kp, pitch, W, H)
+        assert np.array_equal(got, ref)
+        dev = torch.from_numpy(kp.copy()).cuda()                  # device-resident records, in place
+        cabi.check(lib, lib.sba_rotate_keypoints_device(0, C.c_void_p(stream), C.c_void_p(dev.data_ptr()), n, 28,
+                                                        C.c_float(pitch), W, H))
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), ref)
     cube = np.zeros((n, 7), dtype=np.float32)
     cube[:, 0] = rng.uniform(0, 6 * S, n); cube[:, 1] = rng.uniform(0, S, n)
-    cube[:6, 0] = [S / 2 + k * S for k in range(6)]; cube[:6, 1] = S / 2
+    cube[:6, 0] = [S / 2 + k * S for k in range(6)]; cube[:6, 1] = S / 2          # face centres: the two poles among them
+    cube[6:12, 0] = [k * S for k in range(6)]; cube[6:12, 1] = 0.0                # face corners
     got = api.cube2equi_keypoints(cube, S, W, H)
     ref = oracle.cube2equi_keypoints(cube, S, W, H)
-    assert np.abs(got[:, :2] - ref[:, :2]).max() <= 5e-4           # float32 pixels of a 3840-wide image: 1 ulp = 2.4e-4
-    im = rng.integers(0, 256, (480, 960, 3), dtype=np.uint8)
-    for pitch, allowed in ((45.0, 0.0), (-45.0, 0.0), (-90.0, 1e-3)):      # same pixel-boundary ties at -90 as above
-        got = api.crop_rotated_image(im, pitch)
-        ref = oracle.crop_rotated_image(im, pitch)
-        mism = (got != ref).any(axis=2).mean()
-        assert mism <= allowed, f"pitch {pitch}: {mism:.2e} of the pixels differ"
+    assert np.array_equal(got[:, :2].view(np.uint32), ref[:, :2].view(np.uint32))  # bit-identical float32 pixels
+    dev = torch.from_numpy(cube.copy()).cuda()
+    cabi.check(lib, lib.sba_cube2equi_keypoints_device(0, C.c_void_p(stream), C.c_void_p(dev.data_ptr()), n, 28, S, W, H))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # batched, device-resident crop (3 frames)
+    ims = rng.integers(0, 256, (3, 480, 960, 3), dtype=np.uint8)
+    src = torch.from_numpy(ims).cuda()
+    dst = torch.zeros((3, 120, 960, 3), dtype=torch.uint8, device="cuda")
+    cabi.check(lib, lib.sba_crop_rotated_image_device(0, C.c_void_p(stream), C.c_void_p(src.data_ptr()), 480, 960,
+                                                      C.c_float(-90.0), 3, C.c_void_p(dst.data_ptr())))
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(dst[k].cpu().numpy(), oracle.crop_rotated_image(ims[k], -90.0))
     assert api.rotate_keypoints(kp[:0], 45.0, W, H).shape == (0, 7)
+    # odd sizes take the one-pixel-per-lane gather
+    im = rng.integers(0, 256, (50, 101, 3), dtype=np.uint8)
+    assert np.array_equal(api.crop_rotated_image(im, -45.0), oracle.crop_rotated_image(im, -45.0))
 
 
 def test_distributed_attach_one_rank_process_group(oracle):

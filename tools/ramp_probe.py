@@ -20,7 +20,7 @@ with api.Problem(0) as p:
     p.upload(c.x1, c.x2, c.d12)
     kw = dict(depth_mode=api.DEPTH_PER_MATCH)
     t = p.eval_launch_times(api.MODE_RT, c.rot_init, c.tran_init, repeat=400, **kw) * 1e3
-    out["cold_first_400_us"] = [round(float(x), 1) for x in t[:40]] + ["..."] + [round(float(x), 1) for x in t[-5:]]
+    out["cold_first_400_us"] = [round(float(x), 1) for x in t]
     out["cold_mean_first20_us"] = float(t[:20].mean())
     out["cold_mean_last100_us"] = float(t[-100:].mean())
     out["cold_min_us"] = float(t.min())
