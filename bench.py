@@ -52,15 +52,21 @@ def parse():
     ap.add_argument("--precondition-ms", type=float, default=60.0,
                     help="un-timed sweeps of the same kernel before the warm-up steps, to get past the clock dip that "
                          "follows the first ~1.5 ms of load (0 = off); disclosed in the JSON line")
-    ap.add_argument("--workload", choices=["rt", "rot"], default="rt",
-                    help="rt = config C3 (full R|t, per-match depths); rot = config C2 shape (rotation-only)")
+    ap.add_argument("--workload", choices=["rt", "rot", "c5"], default="rt",
+                    help="rt = config C3 / C4 shard (full R|t, per-match depths); rot = config C2 shape (rotation-only); "
+                         "c5 = config C5 (256 ERP pairs x 50k matches per GPU, one batched launch per step, per-pair LM, "
+                         "equi2cube of 512 frames)")
+    ap.add_argument("--pairs", type=int, default=256, help="c5: ERP pairs per GPU")
+    ap.add_argument("--pair-matches", type=int, default=50_000, help="c5: matches per pair")
+    ap.add_argument("--frames", type=int, default=512, help="c5: 3840x1920 ERP frames remapped to S = 600 cube strips")
     ap.add_argument("--store", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--transport", choices=["auto", "peer", "rccl", "hook"], default="rccl",
-                    help="N > 1: exchange of the 24-double pack per step.  rccl (default) = ncclAllReduce from the shim, "
-                         "what north_star names; auto = rccl, else torch.distributed hook; peer = direct xGMI exchange")
+    ap.add_argument("--transport", choices=["auto", "peer", "rccl", "hook"], default="auto",
+                    help="N > 1: exchange of the 24-double pack per step.  auto (default) = rccl (ncclAllReduce issued by "
+                         "the shim: what north_star names) and, only if RCCL cannot be set up on every rank, the "
+                         "torch.distributed hook; rccl = RCCL or fail; peer = direct xGMI exchange (opt-in)")
     ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
     return ap.parse_args()
 
@@ -135,8 +141,163 @@ def pmc_traffic(kernel_sig: str, n: int):
         return None
 
 
+def run_c5(a):
+    """BASELINE config C5: 256 independent ERP pairs x 50k matches on each GPU.  A step = ONE batched pass over all pairs:
+    per-pair sweep state prepared on the device, batch_sweep_kernel (every pair at its own R|t), fold + moment conversion
+    + publication, packs awaited by the host.  Pairs are independent: N > 1 needs no collective."""
+    import numpy as np
+    import torch
+
+    from spherical_bundle_adjuster_amd import _cabi as cabi
+    from spherical_bundle_adjuster_amd import api, synthetic
+    import ctypes as C
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rehearsal = os.environ.get("SBA_BENCH_ONE_GPU") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)    # control only: the data path has no exchange
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    B, n = a.pairs, a.pair_matches
+    cs = [synthetic.full_rt(n, seed=7000 + rank * B + g) for g in range(B)]
+    off = (np.arange(B + 1) * n).astype(np.uint64)
+    x1, x2, d12 = (np.concatenate([getattr(c, k) for c in cs]) for k in ("x1", "x2", "d12"))
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    kw = dict(depth_mode=api.DEPTH_PER_MATCH)
+    with api.Batch(device_index) as b:
+        t_up = time.perf_counter()
+        b.upload(x1, x2, off, d12)
+        upload_s = time.perf_counter() - t_up
+        barrier()
+        precond = {"sweeps": 0, "ms": 0.0}
+        if a.precondition_ms > 0:
+            t_pc = time.perf_counter()
+            while (time.perf_counter() - t_pc) * 1e3 < a.precondition_ms:
+                b.sweep_launch_times(api.MODE_RT, rot0, tran0, repeat=50, **kw)
+                precond["sweeps"] += 50
+            precond["ms"] = (time.perf_counter() - t_pc) * 1e3
+            barrier()
+        if a.warmup > 0:
+            b.eval_timed(api.MODE_RT, rot0, tran0, a.warmup, **kw)
+        barrier()
+        t0 = time.perf_counter()
+        packs, split = b.eval_timed(api.MODE_RT, rot0, tran0, a.steps, **kw)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_launch = b.sweep_launch_times(api.MODE_RT, rot0, tran0, repeat=max(a.steps, 20), **kw)
+        # per-pair LM: all pairs solved in lock-step off the batched launches
+        opt = api.default_lm_options(tran_param=api.TRAN_SPHERE)
+        b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
+        t_lm = time.perf_counter()
+        rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
+        lm_s = time.perf_counter() - t_lm
+        bpp = b.blocks_per_pair
+    remap = None
+    if rank == 0 and a.frames > 0:
+        # "equi2cube remap on GPU": device-resident frames, 3840x1920 -> S = 600 strip, 6 B per output pixel
+        lib = cabi.load_library()
+        F, H, W, S = a.frames, 1920, 3840, 600
+        src = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros((F, S, 6 * S, 3), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        call = lambda: cabi.check(lib, lib.sba_equi2cube_device(device_index, C.c_void_p(st), C.c_void_p(src.data_ptr()), H, W,
+                                                                 S, F, C.c_void_p(dst.data_ptr())))
+        call(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        remap = {"frames": F, "ms_per_batch": ms, "frames_per_s": F / (ms * 1e-3),
+                 "algorithmic_GBps": F * S * 6 * S * 6 / (ms * 1e-3) / 1e9,
+                 "what": "sba_equi2cube_device: 3840x1920 8UC3 frames -> 600 x 3600 strips, 3 B gathered + 3 B stored per pixel"}
+        del src, dst
+    if rank == 0:
+        total = B * n * world
+        sweep_ms = float(per_launch.mean())
+        achieved = B * n * 64 / (sweep_ms * 1e-3) / 1e9
+        out = {
+            "metric": "residual+Jacobian evals/sec", "value": total * a.steps / elapsed, "unit": "evals/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" + (" (ONE-GPU REHEARSAL of the multi-rank path: not a measurement)" if rehearsal else ""),
+            "config": {"workload": f"{B} ERP pairs x {n} matches per GPU, batched full R|t sweep with per-match depths, one "
+                                   "launch for all pairs, per-pair LM (BASELINE config C5)",
+                       "pairs_per_gpu": B, "matches_per_pair": n, "bytes_per_eval": 64, "blocks_per_pair": bpp,
+                       "allreduce": "none (pairs are independent)",
+                       "step": "prepare kernel (per-pair sweep state) + batch_sweep_kernel + fold/convert/publish kernel, packs awaited by the host"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_named("batch_sweep_kernel", B * n),
+                         "kernel": "batch_sweep_kernel<2, 1, double, 0, true>", "kernel_ms": sweep_ms,
+                         "kernel_ms_what": f"mean of {len(per_launch)} launches, HIP event between every two",
+                         "kernel_ms_min": float(per_launch.min()), "kernel_ms_median": float(np.median(per_launch)),
+                         "kernel_ms_max": float(per_launch.max()),
+                         "algorithmic_bytes_per_launch": B * n * 64},
+            "preconditioning": {**precond, "what": "un-timed launches of the same kernel before the warm-up steps"},
+            "step_split_ms": split,
+            "lm": {"pairs_per_s": B / lm_s, "seconds": lm_s, "seconds_inside_the_library": max(s_.seconds_total for s_ in sums),
+                   "max_iterations": max(s_.num_iterations for s_ in sums),
+                   "all_converged": bool((status == 0).all() and all(s_.termination.startswith("CONV") for s_ in sums)),
+                   "max_rot_err_rad": float(max(np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)))},
+            "equi2cube": remap, "upload_s": upload_s,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            from oracle import oracle_py as orc
+            cores = min(orc.num_procs(), usable_cores())
+            take = max(1, min(B, a.cpu_sample // n))
+            passes, t0 = 0, time.perf_counter()
+            while True:
+                for g in range(take):
+                    orc.evaluate_f64(2, cs[g].x1, cs[g].x2, cs[g].rot_init, cs[g].tran_init, 1.0, 1.0, 1.0, cs[g].d12, threads=cores)
+                passes += 1
+                el = time.perf_counter() - t0
+                if el >= a.cpu_seconds or passes >= 50:
+                    break
+            out["cpu_baseline"] = {"value": take * n * passes / el, "unit": "evals/s", "cores": cores, "kind": "port",
+                                   "sample": f"{passes} passes over the first {take} pairs ({take * n} correspondences), faithful "
+                                             f"dual-number loop with f64 accumulation, {cores} OpenMP threads"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pmc_traffic_named(kernel_prefix: str, units: int):
+    """HBM bytes per launch of a secondary kernel from the committed stage profile (profiles/pmc_stages_latest.json)."""
+    try:
+        d = json.loads((ROOT / "profiles" / "pmc_stages_latest.json").read_text())
+        for k, v in d["kernels"].items():
+            if k.startswith(kernel_prefix) and v.get("units_per_launch") == units:
+                return v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     a = parse()
+    if a.workload == "c5":
+        return run_c5(a)
     if a.n <= 0:
         a.n = 10_000_000 if a.gpus == 1 else 12_500_000
     import numpy as np

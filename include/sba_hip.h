@@ -364,6 +364,10 @@ int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* r
                          const double* d1, const double* d2, double huber_delta, int steps, double* packs,
                          double* mean_step_ms, double* mean_prepare_ms, double* mean_device_ms,
                          double* mean_convert_ms);
+/* The batched sweep kernel alone, `repeat` launches with a HIP event between every two (as
+ * sba_problem_eval_launch_times): launch_ms[i] = device time of launch i.  repeat <= 4096.                        */
+int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                                 const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms);
 /* rot / tran are updated in place per pair; summaries (sba_lm_summary[num_pairs]) and status
  * (int[num_pairs], SBA_OK or SBA_ERR_NUMERIC per pair) may be NULL.                                        */
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,

@@ -394,6 +394,18 @@ class Batch:
             *[C.cast(C.byref(m), C.POINTER(C.c_double)) for m in ms]))
         return packs, dict(zip(("step_ms", "prepare_ms", "device_ms", "convert_ms"), (m.value for m in ms)))
 
+    def sweep_launch_times(self, mode, rot, tran, d1=None, d2=None, huber_delta=1.0, depth_mode=DEPTH_UNIFORM,
+                           repeat: int = 20) -> np.ndarray:
+        """Device time (ms) of each of `repeat` back-to-back launches of the batched sweep kernel alone."""
+        rot, rp = self._pp(rot, 3)
+        tran, tp = self._pp(tran, 3)
+        d1a, d1p = self._pp(d1, 1)
+        d2a, d2p = self._pp(d2, 1)
+        ms = np.zeros(repeat, dtype=np.float32)
+        cabi.check(self._lib, self._lib.sba_batch_sweep_launch_times(
+            self._h, mode, depth_mode, rp, tp, d1p, d2p, huber_delta, repeat, ms.ctypes.data_as(C.POINTER(C.c_float))))
+        return ms.astype(np.float64)
+
     def solve(self, mode, rot, tran, d1=None, d2=None, depth_mode=DEPTH_UNIFORM, options: cabi.LmOptions | None = None):
         """Per-pair LM in lock-step.  Returns (rot (B,3), tran (B,3), [SolveSummary], status (B,))."""
         rot = _f64(rot).reshape(self.num_pairs, 3).copy()

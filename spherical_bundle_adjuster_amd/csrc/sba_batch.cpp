@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -32,6 +33,9 @@ struct sba_batch {
   size_t total_vecs = 0;
   void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* dplane[2] = {nullptr, nullptr};
+  void* plane_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipMalloc'ed blocks
+  size_t plane_stagger = 4352;   // plane k starts k * 4352 B into its allocation (as sba_problem: equal element indices of
+                                 // the 8 streams then differ in their low address bits); SBA_PLANE_STAGGER overrides
   sba::PairDesc* desc_dev = nullptr;
   sba::SweepParams* params_dev = nullptr;    // built on the device by batch_prepare_kernel
   sba::BatchState* state_host = nullptr;     // pinned + mapped: what the host hands over per pair and step (80 B)
@@ -44,13 +48,16 @@ struct sba_batch {
   double* packs_host_dev = nullptr;           // device-visible address of packs_host
   unsigned long long seq = 0;                 // launches published so far
   bool publish = true;                        // SBA_PUBLISH=0: D2H copy + stream synchronise instead
+  sba::BatchLmIo* lm_io_host = nullptr;       // pinned + mapped: per-pair start point in, result + summary out (batch_lm_kernel)
+  sba::BatchLmIo* lm_io_host_dev = nullptr;   // device-visible address of lm_io_host
 };
 
 namespace {
 
 int free_batch_data(sba_batch* b) {
-  for (auto& c : b->coord) { if (c) SBA_TRY_HIP(hipFree(c)); c = nullptr; }
-  for (auto& d : b->dplane) { if (d) SBA_TRY_HIP(hipFree(d)); d = nullptr; }
+  for (auto& pb : b->plane_base) { if (pb) SBA_TRY_HIP(hipFree(pb)); pb = nullptr; }
+  for (auto& c : b->coord) c = nullptr;
+  for (auto& d : b->dplane) d = nullptr;
   if (b->desc_dev) SBA_TRY_HIP(hipFree(b->desc_dev));
   if (b->params_dev) SBA_TRY_HIP(hipFree(b->params_dev));
   if (b->state_host) SBA_TRY_HIP(hipHostFree(b->state_host));
@@ -58,6 +65,8 @@ int free_batch_data(sba_batch* b) {
   if (b->partials) SBA_TRY_HIP(hipFree(b->partials));
   if (b->packs_dev) SBA_TRY_HIP(hipFree(b->packs_dev));
   if (b->packs_host) SBA_TRY_HIP(hipHostFree(b->packs_host));
+  if (b->lm_io_host) SBA_TRY_HIP(hipHostFree(b->lm_io_host));
+  b->lm_io_host = nullptr; b->lm_io_host_dev = nullptr;
   b->desc_dev = nullptr; b->params_dev = nullptr; b->state_host = nullptr; b->state_host_dev = nullptr;
   b->frames_dev = nullptr; b->partials = nullptr;
   b->packs_dev = nullptr; b->packs_host = nullptr; b->packs_host_dev = nullptr;
@@ -180,7 +189,12 @@ int sba_batch_create(sba_batch** out, int device, void* stream) {
                           e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
   if (device < 0 || device >= count) return sba::set_error(SBA_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, count);
   SBA_TRY_HIP(hipSetDevice(device));
-  sba_batch* b = new sba_batch();
+  struct Guard {      // any failing HIP call below releases what was created so far
+    sba_batch* b;
+    ~Guard() { if (b) (void)sba_batch_destroy(b); }
+  } guard{new (std::nothrow) sba_batch()};
+  sba_batch* b = guard.b;
+  if (!b) return sba::set_error(SBA_ERR_HIP, "out of host memory");
   b->device = device;
   hipDeviceProp_t prop;
   SBA_TRY_HIP(hipGetDeviceProperties(&prop, device));
@@ -188,12 +202,17 @@ int sba_batch_create(sba_batch** out, int device, void* stream) {
   if (const char* env = std::getenv("SBA_KERNEL"))
     if (std::strcmp(env, "explicit") == 0) b->kind = SBA_KERNEL_EXPLICIT;
   if (const char* env = std::getenv("SBA_PUBLISH")) b->publish = std::strcmp(env, "0") != 0;
+  if (const char* env = std::getenv("SBA_PLANE_STAGGER")) {
+    const long v = std::atol(env);
+    if (v >= 0 && v <= (1 << 20) && v % 16 == 0) b->plane_stagger = static_cast<size_t>(v);
+  }
   if (stream) {
     b->stream = static_cast<hipStream_t>(stream);
   } else {
     SBA_TRY_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     b->own_stream = true;
   }
+  guard.b = nullptr;     // hand over
   *out = b;
   return SBA_OK;
 }
@@ -201,7 +220,7 @@ int sba_batch_create(sba_batch** out, int device, void* stream) {
 int sba_batch_destroy(sba_batch* b) {
   if (!b) return SBA_OK;
   (void)hipSetDevice(b->device);
-  (void)hipStreamSynchronize(b->stream);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
   free_batch_data(b);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -247,14 +266,18 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   }
   b->total_vecs = vec + 1;
   const size_t elems = b->total_vecs * ppt, esz = store == SBA_STORE_F64 ? 8 : 4;
-  for (auto& c : b->coord) {
-    SBA_TRY_HIP(hipMalloc(&c, elems * esz));
-    SBA_TRY_HIP(hipMemsetAsync(c, 0, elems * esz, b->stream));
+  for (int k = 0; k < 6; ++k) {
+    const size_t lead = b->plane_stagger * static_cast<size_t>(k);
+    SBA_TRY_HIP(hipMalloc(&b->plane_base[k], lead + elems * esz));
+    SBA_TRY_HIP(hipMemsetAsync(b->plane_base[k], 0, lead + elems * esz, b->stream));
+    b->coord[k] = static_cast<char*>(b->plane_base[k]) + lead;
   }
   if (d12)
-    for (auto& d : b->dplane) {
-      SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&d), elems * 8));
-      SBA_TRY_HIP(hipMemsetAsync(d, 0, elems * 8, b->stream));
+    for (int k = 0; k < 2; ++k) {
+      const size_t lead = b->plane_stagger * static_cast<size_t>(6 + k);
+      SBA_TRY_HIP(hipMalloc(&b->plane_base[6 + k], lead + elems * 8));
+      SBA_TRY_HIP(hipMemsetAsync(b->plane_base[6 + k], 0, lead + elems * 8, b->stream));
+      b->dplane[k] = reinterpret_cast<double*>(static_cast<char*>(b->plane_base[6 + k]) + lead);
     }
   if (num_pairs == 0) { b->uploaded = true; return SBA_OK; }
 
@@ -280,6 +303,10 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
                             hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(b->packs_host, 0, sizeof(double) * (24 * num_pairs + 8));
   SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->packs_host_dev), b->packs_host, 0));
+  SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->lm_io_host), sizeof(sba::BatchLmIo) * num_pairs,
+                            hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(b->lm_io_host, 0, sizeof(sba::BatchLmIo) * num_pairs);
+  SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->lm_io_host_dev), b->lm_io_host, 0));
   b->seq = 0;
 
   // stage the AoS arrays whole, then re-lay each pair out at its plane offset
@@ -362,6 +389,36 @@ int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* r
   return SBA_OK;
 }
 
+int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                                 const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms) {
+  int rc = check_batch_args(b, mode, depth_mode, rot, tran);
+  if (rc) return rc;
+  if (!launch_ms || repeat < 1 || repeat > 4096) return sba::set_error(SBA_ERR_INVALID_ARG, "bad launch_ms/repeat (1..4096)");
+  if (b->num_pairs == 0) { for (int i = 0; i < repeat; ++i) launch_ms[i] = 0.f; return SBA_OK; }
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  rc = batch_launch(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, nullptr);   // leaves params_dev prepared
+  if (rc) return rc;
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
+  pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+  } events;
+  events.ev.assign(static_cast<size_t>(repeat) + 1, nullptr);
+  for (hipEvent_t& e : events.ev) SBA_TRY_HIP(hipEventCreate(&e));
+  SBA_TRY_HIP(hipEventRecord(events.ev[0], b->stream));
+  for (int i = 0; i < repeat; ++i) {
+    SBA_TRY_HIP(sba::launch_batch_sweep_only(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
+                                             b->desc_dev, b->num_pairs, b->bpp, b->partials, b->stream));
+    SBA_TRY_HIP(hipEventRecord(events.ev[static_cast<size_t>(i) + 1], b->stream));
+  }
+  SBA_TRY_HIP(hipEventSynchronize(events.ev[static_cast<size_t>(repeat)]));
+  for (int i = 0; i < repeat; ++i)
+    SBA_TRY_HIP(hipEventElapsedTime(&launch_ms[i], events.ev[static_cast<size_t>(i)], events.ev[static_cast<size_t>(i) + 1]));
+  return SBA_OK;
+}
+
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,
                     const double* d2, const sba_lm_options* opt, sba_lm_summary* summaries, int* status) {
   int rc = check_batch_args(b, mode, depth_mode, rot, tran);
@@ -372,6 +429,41 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
   sba_lm_options o;
   if (opt) o = *opt; else sba::lm_default_options(&o);
   o.verbose = 0;   // 256 interleaved progress tables help nobody
+  // One block per pair (at least one pair per CU: config C5): a pair's sweep is reduced entirely inside its block, so its
+  // whole Levenberg-Marquardt solve runs on the device in ONE launch (batch_lm_kernel: the same LmSolver source, one
+  // solver per pair, no host round trip, no lock-step).  SBA_BATCH_DEVICE_LM=0 keeps the host lock-step loop below,
+  // which also serves batches that spread a pair over several blocks.
+  bool device_lm = b->bpp == 1;
+  if (const char* env = std::getenv("SBA_BATCH_DEVICE_LM")) device_lm = device_lm && std::strcmp(env, "0") != 0;
+  if (device_lm) {
+    const auto t0 = std::chrono::steady_clock::now();
+    // start points go to the device through mapped pinned memory (thread 0 of every block reads its own record once,
+    // and writes the result back there at the end): no allocation, no copies -- one launch and one synchronise
+    sba::BatchLmIo* io = b->lm_io_host;
+    for (int g = 0; g < B; ++g) {
+      for (int a = 0; a < 3; ++a) { io[g].rot[a] = rot[3 * g + a]; io[g].tran[a] = tran[3 * g + a]; }
+      io[g].d1 = d1 ? d1[g] : 1.0;
+      io[g].d2 = d2 ? d2[g] : 1.0;
+      io[g].summary = sba_lm_summary{};
+      io[g].status = SBA_ERR_NUMERIC;
+      io[g].pad_ = 0;
+    }
+    sba::Planes pl;
+    for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
+    pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+    SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B, b->stream));
+    SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int failures = 0;
+    for (int g = 0; g < B; ++g) {
+      for (int a = 0; a < 3; ++a) { rot[3 * g + a] = io[g].rot[a]; tran[3 * g + a] = io[g].tran[a]; }
+      if (summaries) { summaries[g] = io[g].summary; summaries[g].seconds_total = seconds; }   // wall clock of the whole batch
+      if (status) status[g] = io[g].status;
+      if (io[g].status != SBA_OK) ++failures;
+    }
+    if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed (see per-pair status)", failures, B);
+    return SBA_OK;
+  }
   std::vector<sba::LmSolver> solver(B);
   std::vector<unsigned char> active(B, 1);
   std::vector<double> qrot(3 * B), qtran(3 * B);

@@ -1,6 +1,9 @@
 // Batched kernels (BASELINE config C5): many independent two-view problems ("pairs") per launch -- the batched sweep,
 // the per-pair preparation of the sweep state, and the fold + moment conversion + publication of all packs.
 // Device core shared with the single-problem sweep: sba_sweep_core.hpp.
+#include <new>
+
+#include "sba_lm.hpp"
 #include "sba_sweep_core.hpp"
 
 namespace sba {
@@ -175,6 +178,107 @@ __global__ __launch_bounds__(1024) void batch_convert_finalize_kernel(const doub
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + items), seq, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// ---- the whole per-pair solve in ONE launch ---------------------------------------------------------------------
+// With one block per pair (bpp == 1: at least one pair per CU, config C5) a pair's sweep is reduced completely inside
+// its block, so nothing about its Levenberg-Marquardt iteration needs another block -- or the host.  Block g runs pair
+// g's entire solve: thread 0 owns an LmSolver (the same __host__ __device__ source the host path runs, csrc/sba_lm.hpp)
+// in LDS; per iteration it turns the solver's query point into the sweep state (fill_sweep_params, factored_frame),
+// all 256 threads sweep the pair's matches with that state held in registers, the block folds its 24 sums, thread 0
+// maps the moments to normal equations (moments_to_normal_pack) and feeds the solver.  No host round trip, no
+// prepare / convert launches, no lock-step between pairs: a block leaves when its pair has converged.  The loop is
+// bounded by the solver itself (max_num_iterations + 1 evaluations, every code path of LmSolver::feed either advances
+// the iteration counter or terminates).
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairDesc* __restrict__ desc,
+                                                         BatchLmIo* __restrict__ io, sba_lm_options opt) {
+  constexpr int NACC = AccMap<MODE, KIND>::N;
+  constexpr int PPT = Lanes<ST>::PPT;
+  __shared__ double wave_out[(kBlock / 64) * 24];
+  __shared__ double raw_s[24];
+  __shared__ SweepParams prm_s;
+  __shared__ double frame_s[18];
+  __shared__ int done_s;
+  __shared__ alignas(16) unsigned char solver_mem[sizeof(LmSolver)];
+  LmSolver* solver = reinterpret_cast<LmSolver*>(solver_mem);
+  const int tid = threadIdx.x;
+  const unsigned pair = blockIdx.x;
+  const size_t n = desc[pair].n, first = desc[pair].first_vec;
+  const size_t nfull = n / PPT;
+  __shared__ double depth_s[2];
+  if (tid == 0) {
+    // io lives in mapped HOST memory: one read of the pair's record here, one write of its result at the end
+    const BatchLmIo in = io[pair];
+    depth_s[0] = in.d1; depth_s[1] = in.d2;
+    new (solver) LmSolver();
+    solver->start(MODE, in.rot, in.tran, opt);
+  }
+  for (;;) {
+    if (tid == 0) {
+      done_s = solver->done() ? 1 : 0;
+      if (!done_s) {
+        fill_sweep_params(n, DEPTH, solver->query_rot(), solver->query_tran(), depth_s[0], depth_s[1], opt.huber_delta, &prm_s);
+        if (KIND == KIND_FACTORED && MODE != MODE_TRAN) factored_frame(solver->query_rot(), frame_s, frame_s + 9);
+      }
+    }
+    __syncthreads();
+    if (done_s) break;
+    const SweepParams prm = prm_s;        // LDS broadcast -> registers, held across the sweep
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    size_t p = tid;
+    VecRegs<ST, DEPTH> cur, nxt;
+    if (p < nfull) cur.load(pl, first + p);
+    while (p < nfull) {
+      const size_t pn = p + kBlock;
+      if (pn < nfull) nxt.load(pl, first + pn);
+      consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, &prm, p, n, acc);
+      cur = nxt;
+      p = pn;
+    }
+    if (nfull * PPT != n && tid == kBlock - 1) {
+      cur.load(pl, first + nfull);
+      consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, &prm, nfull, n, acc);
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid < 24) raw_s[tid] = 0.0;       // slots no accumulator maps to stay zero
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      const double sw = wave_sum_to_lane63(acc[k]);
+      if (lane == 63) wave_out[wave * 24 + AccMap<MODE, KIND>::slot(k)] = sw;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+      const int slot = AccMap<MODE, KIND>::slot(tid);
+      double sum = wave_out[slot];
+#pragma unroll
+      for (int wv = 1; wv < kBlock / 64; ++wv) sum += wave_out[wv * 24 + slot];     // same fold order as the 3-kernel path
+      raw_s[slot] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double pack[24];
+      if (KIND == KIND_FACTORED && MODE != MODE_TRAN)
+        moments_to_normal_pack(true, MODE == MODE_RT, frame_s, frame_s + 9, raw_s, pack);
+      else
+        for (int k = 0; k < 24; ++k) pack[k] = raw_s[k];
+      sba_normal_eq ne;
+      expand_pack(MODE, pack, &ne);
+      solver->feed(ne);
+    }
+    // thread 0 re-enters the loop head alone; everybody else waits at its barrier
+  }
+  if (tid == 0) {
+    BatchLmIo res;
+    for (int a = 0; a < 3; ++a) { res.rot[a] = solver->rot()[a]; res.tran[a] = solver->tran()[a]; }
+    res.d1 = depth_s[0]; res.d2 = depth_s[1];
+    res.summary = solver->summary();
+    res.status = solver->status();
+    res.pad_ = 0;
+    io[pair] = res;
+  }
+}
+
 // ---- batch kernel table (same template axes as the single-problem sweep) ---------------------------------------
 typedef void (*BatchFn)(Planes, const SweepParams*, const PairDesc*, int, double*);
 template <int MODE, int DEPTH, typename ST, int KIND>
@@ -202,7 +306,42 @@ BatchFn bpick(int mode, int depth, int store, int kind, bool loss) {
   return nullptr;
 }
 
+typedef void (*BatchLmFn)(Planes, const PairDesc*, BatchLmIo*, sba_lm_options);
+template <int MODE, int DEPTH, typename ST, int KIND>
+BatchLmFn lpick_loss(bool loss) {
+  return loss ? batch_lm_kernel<MODE, DEPTH, ST, KIND, true> : batch_lm_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+BatchLmFn lpick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? lpick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss)
+                               : lpick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
+template <int MODE, int DEPTH>
+BatchLmFn lpick_store(int store, int kind, bool loss) {
+  return store == 0 ? lpick_kind<MODE, DEPTH, double>(kind, loss) : lpick_kind<MODE, DEPTH, float>(kind, loss);
+}
+BatchLmFn lpick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return lpick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return lpick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return lpick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return lpick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return lpick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return lpick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
+}
+
 }  // namespace
+
+hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
+                           BatchLmIo* io, const sba_lm_options& opt, int num_pairs, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchLmFn fn = lpick(mode, depth, store, kind, opt.huber_delta > 0.0);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs)), dim3(kBlock), 0, stream, pl, desc, io, opt);
+  return hipGetLastError();
+}
 
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks) {
   BatchFn fn = bpick(mode, depth, store, kind, loss);
@@ -223,6 +362,18 @@ hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool los
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
                      packs_host, seq);
+  return hipGetLastError();
+}
+
+// The batched sweep kernel alone (params already prepared on the device), no fold: timing primitive.
+hipError_t launch_batch_sweep_only(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
+                                   const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
+                                   double* partials, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchFn fn = bpick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs) * bpp), dim3(kBlock), 0, stream, pl, params, desc,
+                     bpp, partials);
   return hipGetLastError();
 }
 

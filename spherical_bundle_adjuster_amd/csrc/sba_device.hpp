@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "../../include/sba_hip.h"
 #include "sba_rotation.hpp"
 
 namespace sba {
@@ -117,6 +118,17 @@ struct BatchState {
   unsigned long long pad_;
 };
 static_assert(sizeof(BatchState) == 80, "BatchState is copied word by word");
+// In / out record of one pair for the one-launch per-pair solve (batch_lm_kernel): start point and uniform depths in,
+// result, summary and status out.
+struct BatchLmIo {
+  double rot[3], tran[3];
+  double d1, d2;
+  sba_lm_summary summary;
+  int status;
+  int pad_;
+};
+hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
+                           BatchLmIo* io, const sba_lm_options& opt, int num_pairs, hipStream_t stream);
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
@@ -125,6 +137,9 @@ hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool los
 // Same, with the per-pair preparation and conversion on the device: batch_prepare_kernel builds every pair's
 // SweepParams (and, for the factored kernel, the frame (B, J) of its rotation) from `state`; batch_finalize_kernel folds
 // the rows and maps the factored kernel's moments to the SBA_PACK_* layout before publishing.
+hipError_t launch_batch_sweep_only(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
+                                   const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
+                                   double* partials, hipStream_t stream);
 hipError_t launch_batch_step(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
                              const BatchState* state, SweepParams* params, double* frames, const PairDesc* desc,
                              int num_pairs, int bpp, double* partials, double* packs, double* packs_host,

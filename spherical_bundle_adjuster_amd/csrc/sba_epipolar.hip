@@ -1,8 +1,15 @@
 // Device pass of the 8-point initial guess (reference spherical_bundle_adjuster.cpp:53-68: one row
 // kron(left_i, right_i) of the N x 9 matrix A per match).  Instead of materialising A for 80 random subsets and
-// running 80 SVDs of (N/4) x 9 matrices, one sweep accumulates A^T A (45 sums) separately for 64 interleaved
-// groups of matches, group(i) = (i / 4) % 64: a lane always handles 4 consecutive matches and keeps its own 45
-// accumulators, so lane id == group id and no cross-lane reduction is needed at all.  One-wave blocks; the rows of
+// running 80 SVDs of (N/4) x 9 matrices, one sweep accumulates A^T A separately for 64 interleaved groups of matches,
+// group(i) = (i / 4) % 64: a lane always handles 4 consecutive matches and keeps its own accumulators, so lane id ==
+// group id and no cross-lane reduction is needed at all.
+//
+// Kronecker structure: entry ((p,q),(r,s)) of A^T A is sum l_p r_q l_r r_s = sum P_pr Q_qs with P = l l^T, Q = r r^T
+// symmetric -- only 6 x 6 = 36 DISTINCT sums (the 45 entries of the upper triangle repeat 9 of them).  36 accumulators
+// and 12 + 36 multiply-adds per match instead of 45 and 9 + 45; the fold kernel writes the 45-entry layout.
+//
+// 256-thread blocks: the four waves of a block stream different quads of matches for the SAME 64 groups and combine
+// through LDS at the end (fixed order), so four times the loads are in flight per row of partials written.  The rows of
 // all blocks are folded per (group, entry) by epipolar_fold_kernel in a fixed order.  Reads the same planes as the
 // sweep kernel (48 B per match), once per problem -- not on the per-iteration path.
 #include "sba_device.hpp"
@@ -10,21 +17,31 @@
 namespace sba {
 namespace {
 
-constexpr int kMom = 45;
+constexpr int kMom = 45;     // upper triangle of the 9 x 9 matrix (what the host consumes)
+constexpr int kSums = 36;    // distinct sums
 
 __device__ __forceinline__ void add_match(double x, double y, double z, double u, double v, double w,
                                           double* __restrict__ acc) {
-  // row of A: left (x) right, .cpp:59-67
-  const double a[9] = {x * u, x * v, x * w, y * u, y * v, y * w, z * u, z * v, z * w};
-  int k = 0;
+  // P = left left^T, Q = right right^T (upper triangles 00 01 02 11 12 22); row of A: left (x) right, .cpp:59-67
+  const double P[6] = {x * x, x * y, x * z, y * y, y * z, z * z};
+  const double Q[6] = {u * u, u * v, u * w, v * v, v * w, w * w};
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
+  for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int j = i; j < 9; ++j) {
-      acc[k] = __builtin_fma(a[i], a[j], acc[k]);
-      ++k;
-    }
+    for (int b = 0; b < 6; ++b) acc[a * 6 + b] = __builtin_fma(P[a], Q[b], acc[a * 6 + b]);
 }
+
+// which of the 36 sums is entry k of the 45 (upper triangle, row-major i <= j over i = 3 p + q, j = 3 r + s)
+struct EntryMap { int src[kMom]; };
+constexpr int sym6(int a, int b) { return a <= b ? (a == 0 ? b : (a == 1 ? 2 + b : 5)) : sym6(b, a); }
+constexpr EntryMap make_entry_map() {
+  EntryMap m{};
+  int k = 0;
+  for (int i = 0; i < 9; ++i)
+    for (int j = i; j < 9; ++j) m.src[k++] = sym6(i / 3, j / 3) * 6 + sym6(i % 3, j % 3);
+  return m;
+}
+__constant__ EntryMap kEntryMap = make_entry_map();
 
 template <typename ST>
 __device__ __forceinline__ void load4(const void* plane, size_t quad, double out[4]);
@@ -42,17 +59,20 @@ __device__ __forceinline__ void load4<float>(const void* plane, size_t quad, dou
   out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
 }
 
-// partials[block][entry][lane]  (entry-major so that the 64 lanes store 512 contiguous bytes per entry)
+// partials[block][sum][lane]  (sum-major so that the 64 lanes store 512 contiguous bytes per sum)
 template <typename ST>
-__global__ __launch_bounds__(64) void epipolar_moments_kernel(Planes pl, unsigned long long n,
-                                                              double* __restrict__ partials) {
-  double acc[kMom];
+__global__ __launch_bounds__(256) void epipolar_moments_kernel(Planes pl, unsigned long long n,
+                                                               double* __restrict__ partials) {
+  __shared__ double red[2][kSums][64];
+  double acc[kSums];
 #pragma unroll
-  for (int k = 0; k < kMom; ++k) acc[k] = 0.0;
+  for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t nquad = (n + 3) / 4;
-  const size_t stride = static_cast<size_t>(gridDim.x) * 64;
-  // next quad's loads are issued before the current one is consumed (register double buffer, like the sweep kernel)
-  size_t q = static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x;
+  const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+  // quad index = 64 * (something) + lane, so group(quad) = quad % 64 = lane for every wave of every block.
+  // Next quad's loads are issued before the current one is consumed (register double buffer, like the sweep kernel).
+  size_t q = (static_cast<size_t>(blockIdx.x) * 4 + wave) * 64 + lane;
   double cur[6][4], nxt[6][4];
   if (q < nquad) {
 #pragma unroll
@@ -74,12 +94,30 @@ __global__ __launch_bounds__(64) void epipolar_moments_kernel(Planes pl, unsigne
       for (int h = 0; h < 4; ++h) cur[k][h] = nxt[k][h];
     q = qn;
   }
-  double* row = partials + static_cast<size_t>(blockIdx.x) * kMom * 64;
+  // waves 2,3 -> LDS; waves 0,1 add them; wave 1 -> LDS; wave 0 adds and stores the block's row: a fixed order
+  if (wave >= 2) {
 #pragma unroll
-  for (int k = 0; k < kMom; ++k) row[k * 64 + threadIdx.x] = acc[k];
+    for (int k = 0; k < kSums; ++k) red[wave - 2][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] += red[wave][k][lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) red[0][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double* row = partials + static_cast<size_t>(blockIdx.x) * kSums * 64;
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) row[k * 64 + lane] = acc[k] + red[0][k][lane];
+  }
 }
 
-// groups[lane][entry] = sum over blocks of partials[block][entry][lane].  One 1024-thread block per entry: wave s
+// groups[lane][entry] = sum over blocks of partials[block][src(entry)][lane].  One 1024-thread block per entry: wave s
 // folds blocks s, s+16, s+32, ... (four independent accumulators), wave 0 then adds the 16 segment sums in segment
 // order -- a fixed order for a given grid, and 16 x 4 loads in flight per (entry, lane) instead of 4.
 __global__ __launch_bounds__(1024) void epipolar_fold_kernel(const double* __restrict__ partials, int nblocks,
@@ -87,8 +125,8 @@ __global__ __launch_bounds__(1024) void epipolar_fold_kernel(const double* __res
   __shared__ double seg_sum[16][64];
   const int entry = blockIdx.x, lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  const size_t bs = static_cast<size_t>(kMom) * 64;
-  const double* src = partials + static_cast<size_t>(entry) * 64 + lane;
+  const size_t bs = static_cast<size_t>(kSums) * 64;
+  const double* src = partials + static_cast<size_t>(kEntryMap.src[entry]) * 64 + lane;
   int b = seg;
   for (; b + 48 < nblocks; b += 64) {
     s0 += src[static_cast<size_t>(b) * bs];
@@ -109,15 +147,15 @@ __global__ __launch_bounds__(1024) void epipolar_fold_kernel(const double* __res
 
 }  // namespace
 
-// groups_dev: [64][45] doubles; partials: [grid][45][64] doubles scratch.
+// groups_dev: [64][45] doubles; partials: [grid][36][64] doubles scratch (sized for 45 by the caller).
 hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double* partials, int grid,
                                    double* groups_dev, hipStream_t stream) {
   if (grid > 0) {
     if (store == 0)
-      hipLaunchKernelGGL((epipolar_moments_kernel<double>), dim3(grid), dim3(64), 0, stream, pl,
+      hipLaunchKernelGGL((epipolar_moments_kernel<double>), dim3(grid), dim3(256), 0, stream, pl,
                          static_cast<unsigned long long>(n), partials);
     else
-      hipLaunchKernelGGL((epipolar_moments_kernel<float>), dim3(grid), dim3(64), 0, stream, pl,
+      hipLaunchKernelGGL((epipolar_moments_kernel<float>), dim3(grid), dim3(256), 0, stream, pl,
                          static_cast<unsigned long long>(n), partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

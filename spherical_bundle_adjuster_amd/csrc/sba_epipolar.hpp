@@ -287,13 +287,14 @@ inline uint64_t splitmix64(uint64_t& s) {
   return z ^ (z >> 31);
 }
 
-// The groups trial `trial` draws: a partial Fisher-Yates shuffle of 0..63 seeded by (seed, trial).
-inline void trial_groups(uint64_t seed, int trial, int count, int* out) {
+// The groups trial `trial` draws: the first `count` entries of a Fisher-Yates shuffle, seeded by (seed, trial), of the
+// `n_items` candidate groups in `items` (nullptr: 0..n_items-1).  A longer draw extends a shorter one.
+inline void trial_groups(uint64_t seed, int trial, int count, int* out, const int* items = nullptr, int n_items = kGroups) {
   uint64_t s = seed * 0x2545F4914F6CDD1Dull + static_cast<uint64_t>(trial) * 0xD6E8FEB86659FD93ull + 1;
   int perm[kGroups];
-  for (int i = 0; i < kGroups; ++i) perm[i] = i;
-  for (int i = 0; i < count; ++i) {
-    const int j = i + static_cast<int>(splitmix64(s) % static_cast<uint64_t>(kGroups - i));
+  for (int i = 0; i < n_items; ++i) perm[i] = items ? items[i] : i;
+  for (int i = 0; i < count && i < n_items; ++i) {
+    const int j = i + static_cast<int>(splitmix64(s) % static_cast<uint64_t>(n_items - i));
     std::swap(perm[i], perm[j]);
     out[i] = perm[i];
   }
@@ -361,26 +362,49 @@ struct GuessResult {
   std::vector<Candidate> candidates;
 };
 
-// groups: [64][45] moments, counts not needed.  trials / fraction / seed: 80, 0.25 in the reference.
+// groups: [64][45] moments (the match count of a group is the trace of its matrix).  trials / fraction / seed: 80, 0.25
+// in the reference.
 // Trials are independent (the subset of trial k depends on (seed, k) only), so they run on `threads` host threads --
 // what the reference's set_omp(num_proc) does for its loops -- and are collected in trial order: the result does not
 // depend on the thread count.
 inline GuessResult initial_guess_from_groups(const double* groups, int trials, double fraction, uint64_t seed,
                                              int threads = 1) {
   GuessResult res;
-  const int take = std::max(1, std::min(kGroups, static_cast<int>(kGroups * fraction)));
+  // Occupancy of the groups: a row of A is kron(left, right) of two unit vectors, so it has unit length and the trace of
+  // a group's A^T A IS its number of matches.  With fewer than 256 matches some of the 64 groups are empty, and a blind
+  // draw of 16 groups could sum fewer than the 8 correspondences the linear system needs (the reference always takes
+  // floor(n / 4) individual matches, .cpp:132-141): draw among the NON-EMPTY groups -- a quarter of them, like the
+  // reference's quarter of the matches -- and keep drawing until the subset holds at least 8 matches (or every group).
+  // From 256 matches on every group is occupied and holds at least 4: exactly 16 groups, as before.
+  int nonempty[kGroups], count[kGroups], ne = 0;
+  {
+    int diag = 0;
+    int diag_index[9];
+    for (int a = 0; a < 9; ++a) { diag_index[a] = diag; diag += 9 - a; }
+    for (int g = 0; g < kGroups; ++g) {
+      double tr = 0;
+      for (int a = 0; a < 9; ++a) tr += groups[g * kMom + diag_index[a]];
+      count[g] = std::isfinite(tr) && tr > 0.5 ? static_cast<int>(std::lround(tr)) : 0;
+      if (count[g] > 0) nonempty[ne++] = g;
+    }
+  }
+  const int take = std::max(1, std::min(ne, static_cast<int>(ne * fraction)));
   struct TrialOut { Candidate c1, c2; bool v1, v2; };
   std::vector<TrialOut> out(static_cast<size_t>(std::max(trials, 0)));
   auto run = [&](int first, int last) {
     for (int trial = first; trial < last; ++trial) {
-      int sel[kGroups];
-      trial_groups(seed, trial, take, sel);
-      std::sort(sel, sel + take);                     // fixed summation order
-      double mom[kMom] = {0};
-      for (int s = 0; s < take; ++s)
-        for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
       TrialOut& o = out[trial];
       o.c1 = Candidate{}; o.c2 = Candidate{}; o.v1 = o.v2 = false;
+      if (ne == 0) continue;
+      int sel[kGroups];
+      trial_groups(seed, trial, ne, sel, nonempty, ne);
+      int used = take, matches = 0;
+      for (int s = 0; s < used; ++s) matches += count[sel[s]];
+      while (matches < 8 && used < ne) matches += count[sel[used++]];
+      std::sort(sel, sel + used);                     // fixed summation order
+      double mom[kMom] = {0};
+      for (int s = 0; s < used; ++s)
+        for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
       float tv[3];
       trial_from_moments(mom, o.c1.euler, o.c2.euler, tv, &o.v1, &o.v2, nullptr);
       for (int i = 0; i < 3; ++i) o.c1.tran[i] = o.c2.tran[i] = tv[i];

@@ -22,6 +22,11 @@
 //
 // Build extension (SBA_TRAN_SPHERE): the translation moves in the 2-dim tangent plane of the
 // sphere |tran| = const (5-DoF R|t); Ceres users would get this with a local parameterization.
+//
+// The whole solver is __host__ __device__: the host drives one problem (or a lock-step batch) with it, and the batched
+// per-pair kernel (sba_batch_kernels.hip: batch_lm_kernel) runs the very same source on the device, one solver per pair,
+// so that an entire per-pair solve needs no host round trip.  FP contraction is switched off for this header so that both
+// compilations round identically (the host has no FMA contraction to begin with).
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -31,9 +36,25 @@
 
 #include "../../include/sba_hip.h"
 
+#ifndef SBA_HD
+#if defined(__HIPCC__)
+#define SBA_HD __host__ __device__
+#else
+#define SBA_HD
+#endif
+#endif
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT OFF
+#define SBA_UNROLL _Pragma("unroll")
+#elif defined(__GNUC__)
+#define SBA_UNROLL _Pragma("GCC unroll 8")
+#else
+#define SBA_UNROLL
+#endif
+
 namespace sba {
 
-inline void lm_default_options(sba_lm_options* o) {
+SBA_HD inline void lm_default_options(sba_lm_options* o) {
   o->max_num_iterations = 50;
   o->initial_trust_region_radius = 1e4;
   o->max_trust_region_radius = 1e16;
@@ -56,8 +77,8 @@ inline void lm_default_options(sba_lm_options* o) {
 }
 
 // pack (SBA_PACK_* layout) -> symmetric 6x6 over [rot | tran]
-inline void expand_pack(int mode, const double* pack, sba_normal_eq* ne) {
-  std::memset(ne, 0, sizeof(*ne));
+SBA_HD inline void expand_pack(int mode, const double* pack, sba_normal_eq* ne) {
+  *ne = sba_normal_eq{};
   double* H = ne->H;
   if (mode == SBA_MODE_ROT || mode == SBA_MODE_RT) {
     int k = SBA_PACK_HAA;
@@ -88,36 +109,62 @@ inline void expand_pack(int mode, const double* pack, sba_normal_eq* ne) {
 
 namespace detail {
 
-// Cholesky solve of the m x m SPD system A y = b (m <= 6).  Returns false if not SPD.
-inline bool cholesky_solve(int m, const double* A, const double* b, double* y) {
-  double L[36];
-  for (int i = 0; i < m; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double s = A[i * m + j];
-      for (int k = 0; k < j; ++k) s -= L[i * m + k] * L[j * m + k];
-      if (i == j) {
-        if (!(s > 0.0) || !std::isfinite(s)) return false;
-        L[i * m + i] = std::sqrt(s);
-      } else {
-        L[i * m + j] = s / L[j * m + j];
+// All small matrices of the solver are stored with a FIXED row stride of 6 and every loop runs over the full 0..5 range
+// under an `index < m` guard, fully unrolled: indices are then compile-time constants and the arrays live in registers
+// -- on the device a run-time stride would put them in scratch memory, and the one thread that advances a pair's solver
+// (batch_lm_kernel) would spend its time on memory round trips.  Only the order of the arithmetic matters for the
+// result, and that is the plain i, j, k order of the textbook loops.
+constexpr int kDim = 6;
+
+// Cholesky solve of the m x m SPD system A y = b (m <= 6, row stride 6).  Returns false if not SPD.
+SBA_HD inline bool cholesky_solve(int m, const double* A, const double* b, double* y) {
+  double L[kDim * kDim];
+  bool ok = true;
+  SBA_UNROLL
+  for (int i = 0; i < kDim; ++i) {
+    SBA_UNROLL
+    for (int j = 0; j < kDim; ++j) {
+      if (j <= i && i < m && ok) {
+        double s = A[i * kDim + j];
+        SBA_UNROLL
+        for (int k = 0; k < kDim; ++k)
+          if (k < j) s -= L[i * kDim + k] * L[j * kDim + k];
+        if (i == j) {
+          if (!(s > 0.0) || !std::isfinite(s)) ok = false;
+          else L[i * kDim + i] = std::sqrt(s);
+        } else {
+          L[i * kDim + j] = s / L[j * kDim + j];
+        }
       }
     }
-  double z[6];
-  for (int i = 0; i < m; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[i * m + k] * z[k];
-    z[i] = s / L[i * m + i];
   }
-  for (int i = m - 1; i >= 0; --i) {
-    double s = z[i];
-    for (int k = i + 1; k < m; ++k) s -= L[k * m + i] * y[k];
-    y[i] = s / L[i * m + i];
+  if (!ok) return false;
+  double z[kDim];
+  SBA_UNROLL
+  for (int i = 0; i < kDim; ++i) {
+    if (i < m) {
+      double s = b[i];
+      SBA_UNROLL
+      for (int k = 0; k < kDim; ++k)
+        if (k < i) s -= L[i * kDim + k] * z[k];
+      z[i] = s / L[i * kDim + i];
+    }
+  }
+  SBA_UNROLL
+  for (int i = kDim - 1; i >= 0; --i) {
+    if (i < m) {
+      double s = z[i];
+      SBA_UNROLL
+      for (int k = 0; k < kDim; ++k)
+        if (k > i && k < m) s -= L[k * kDim + i] * y[k];
+      y[i] = s / L[i * kDim + i];
+    }
   }
   return true;
 }
 
 // Orthonormal basis B (3x2, columns b0,b1) of the plane perpendicular to t.
-inline void tangent_basis(const double t[3], double B[6]) {
+SBA_HD inline void tangent_basis(const double t[3], double B[6]) {
   const double n = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
   double u[3] = {1, 0, 0};
   if (n > 0) { u[0] = t[0] / n; u[1] = t[1] / n; u[2] = t[2] / n; }
@@ -137,59 +184,86 @@ inline void tangent_basis(const double t[3], double B[6]) {
   }
 }
 
-// The free-parameter view of a mode: P (6 x m) maps a local step to the ambient [rot|tran] step.
+// The free-parameter view of a mode: P (6 x m, row stride 6) maps a local step to the ambient [rot|tran] step.
 struct Param {
   int m = 0;
-  double P[36] = {0};  // row-major 6 x m
+  double P[kDim * kDim] = {0};  // row-major, row stride 6, columns 0..m-1 used
   bool sphere = false;
   double tnorm = 0.0;
-  void build(int mode, int tran_param, const double tran[3]) {
-    std::memset(P, 0, sizeof(P));
+  SBA_HD void build(int mode, int tran_param, const double tran[3]) {
+    SBA_UNROLL
+    for (int i = 0; i < kDim * kDim; ++i) P[i] = 0.0;
     const bool rot = mode != SBA_MODE_TRAN, tr = mode != SBA_MODE_ROT;
     sphere = tr && tran_param == SBA_TRAN_SPHERE;
     m = (rot ? 3 : 0) + (tr ? (sphere ? 2 : 3) : 0);
-    int c = 0;
-    if (rot) { for (int a = 0; a < 3; ++a) P[a * m + (c + a)] = 1.0; c += 3; }
+    const int c = rot ? 3 : 0;     // first translation column
+    if (rot) { P[0 * kDim + 0] = 1.0; P[1 * kDim + 1] = 1.0; P[2 * kDim + 2] = 1.0; }
     if (tr) {
       if (sphere) {
         double B[6];
         tangent_basis(tran, B);
-        for (int r = 0; r < 3; ++r) { P[(3 + r) * m + c] = B[2 * r]; P[(3 + r) * m + c + 1] = B[2 * r + 1]; }
+        SBA_UNROLL
+        for (int r = 0; r < 3; ++r) {
+          if (c == 3) { P[(3 + r) * kDim + 3] = B[2 * r]; P[(3 + r) * kDim + 4] = B[2 * r + 1]; }
+          else { P[(3 + r) * kDim + 0] = B[2 * r]; P[(3 + r) * kDim + 1] = B[2 * r + 1]; }
+        }
         tnorm = std::sqrt(tran[0] * tran[0] + tran[1] * tran[1] + tran[2] * tran[2]);
       } else {
-        for (int a = 0; a < 3; ++a) P[(3 + a) * m + (c + a)] = 1.0;
+        SBA_UNROLL
+        for (int a = 0; a < 3; ++a) {
+          if (c == 3) P[(3 + a) * kDim + 3 + a] = 1.0;
+          else P[(3 + a) * kDim + a] = 1.0;
+        }
       }
     }
   }
-  // Hf = P^T H P, gf = P^T g
-  void project(const sba_normal_eq& ne, double* Hf, double* gf) const {
-    double HP[36];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < m; ++j) {
-        double s = 0;
-        for (int k = 0; k < 6; ++k) s += ne.H[6 * i + k] * P[k * m + j];
-        HP[i * m + j] = s;
+  // Hf = P^T H P, gf = P^T g   (Hf: row stride 6)
+  SBA_HD void project(const sba_normal_eq& ne, double* Hf, double* gf) const {
+    double HP[kDim * kDim];
+    SBA_UNROLL
+    for (int i = 0; i < kDim; ++i) {
+      SBA_UNROLL
+      for (int j = 0; j < kDim; ++j) {
+        if (j < m) {
+          double s = 0;
+          SBA_UNROLL
+          for (int k = 0; k < kDim; ++k) s += ne.H[6 * i + k] * P[k * kDim + j];
+          HP[i * kDim + j] = s;
+        }
       }
-    for (int i = 0; i < m; ++i) {
-      for (int j = 0; j < m; ++j) {
+    }
+    SBA_UNROLL
+    for (int i = 0; i < kDim; ++i) {
+      if (i < m) {
+        SBA_UNROLL
+        for (int j = 0; j < kDim; ++j) {
+          if (j < m) {
+            double s = 0;
+            SBA_UNROLL
+            for (int k = 0; k < kDim; ++k) s += P[k * kDim + i] * HP[k * kDim + j];
+            Hf[i * kDim + j] = s;
+          }
+        }
         double s = 0;
-        for (int k = 0; k < 6; ++k) s += P[k * m + i] * HP[k * m + j];
-        Hf[i * m + j] = s;
+        SBA_UNROLL
+        for (int k = 0; k < kDim; ++k) s += P[k * kDim + i] * ne.g[k];
+        gf[i] = s;
       }
-      double s = 0;
-      for (int k = 0; k < 6; ++k) s += P[k * m + i] * ne.g[k];
-      gf[i] = s;
     }
   }
   // x_plus_delta
-  void plus(const double rot[3], const double tran[3], const double* delta, double rot_out[3],
-            double tran_out[3]) const {
-    double d6[6];
-    for (int i = 0; i < 6; ++i) {
+  SBA_HD void plus(const double rot[3], const double tran[3], const double* delta, double rot_out[3],
+                   double tran_out[3]) const {
+    double d6[kDim];
+    SBA_UNROLL
+    for (int i = 0; i < kDim; ++i) {
       double s = 0;
-      for (int j = 0; j < m; ++j) s += P[i * m + j] * delta[j];
+      SBA_UNROLL
+      for (int j = 0; j < kDim; ++j)
+        if (j < m) s += P[i * kDim + j] * delta[j];
       d6[i] = s;
     }
+    SBA_UNROLL
     for (int a = 0; a < 3; ++a) {
       rot_out[a] = rot[a] + d6[a];
       tran_out[a] = tran[a] + d6[3 + a];
@@ -197,8 +271,10 @@ struct Param {
     if (sphere) {
       const double nn = std::sqrt(tran_out[0] * tran_out[0] + tran_out[1] * tran_out[1] +
                                   tran_out[2] * tran_out[2]);
-      if (nn > 0)
+      if (nn > 0) {
+        SBA_UNROLL
         for (int a = 0; a < 3; ++a) tran_out[a] *= tnorm / nn;
+      }
     }
   }
 };
@@ -208,11 +284,11 @@ struct Param {
 class LmSolver {
  public:
   // After start() and after every feed(): either done() or (query_rot, query_tran) is the point to evaluate next.
-  void start(int mode, const double rot0[3], const double tran0[3], const sba_lm_options& opt) {
+  SBA_HD void start(int mode, const double rot0[3], const double tran0[3], const sba_lm_options& opt) {
     mode_ = mode;
     o_ = opt;
     for (int a = 0; a < 3; ++a) { rot_[a] = qrot_[a] = rot0[a]; tran_[a] = qtran_[a] = tran0[a]; }
-    std::memset(&sum_, 0, sizeof(sum_));
+    sum_ = sba_lm_summary{};
     sum_.termination = SBA_TERM_FAILURE;
     phase_ = kInitial;
     done_ = false;
@@ -223,21 +299,21 @@ class LmSolver {
     invalid_steps_ = 0;
     iter_ = 0;
     gmax_ = 0.0;
-    t_start_ = std::chrono::steady_clock::now();
+    t_start_ = now_seconds();
   }
-  bool done() const { return done_; }
-  int status() const { return rc_; }                 // SBA_OK or SBA_ERR_NUMERIC
-  const double* query_rot() const { return qrot_; }
-  const double* query_tran() const { return qtran_; }
-  const double* rot() const { return rot_; }         // current accepted point (the result once done)
-  const double* tran() const { return tran_; }
-  const sba_lm_summary& summary() const { return sum_; }
+  SBA_HD bool done() const { return done_; }
+  SBA_HD int status() const { return rc_; }                 // SBA_OK or SBA_ERR_NUMERIC
+  SBA_HD const double* query_rot() const { return qrot_; }
+  SBA_HD const double* query_tran() const { return qtran_; }
+  SBA_HD const double* rot() const { return rot_; }         // current accepted point (the result once done)
+  SBA_HD const double* tran() const { return tran_; }
+  SBA_HD const sba_lm_summary& summary() const { return sum_; }
 
   // The evaluation at the query point failed on the device side.
-  void fail() { finish(SBA_TERM_FAILURE, SBA_ERR_NUMERIC); }
+  SBA_HD void fail() { finish(SBA_TERM_FAILURE, SBA_ERR_NUMERIC); }
 
   // Normal equations at (query_rot, query_tran).
-  void feed(const sba_normal_eq& ne) {
+  SBA_HD void feed(const sba_normal_eq& ne) {
     using namespace detail;
     if (done_) return;
     sum_.num_evaluations++;
@@ -247,12 +323,16 @@ class LmSolver {
       sum_.initial_cost = cur_.cost;
       par_.build(mode_, o_.tran_param, tran_);
       par_.project(cur_, Hf_, gf_);
-      for (int i = 0; i < par_.m; ++i)
-        scale_[i] = o_.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(std::max(Hf_[i * par_.m + i], 0.0))) : 1.0;
+      SBA_UNROLL
+      for (int i = 0; i < detail::kDim; ++i)
+        if (i < par_.m)
+          scale_[i] = o_.jacobi_scaling ? 1.0 / (1.0 + std::sqrt(std::max(Hf_[i * detail::kDim + i], 0.0))) : 1.0;
       gmax_ = gmax_of(gf_);
+#if !defined(__HIP_DEVICE_COMPILE__)
       if (o_.verbose)
         std::printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n"
                     "%4d % .6e    0.00e+00    %.2e   0.00e+00   0.00e+00  %.2e\n", 0, cur_.cost, gmax_, radius_);
+#endif
       phase_ = kCandidate;
       next_candidate();
       return;
@@ -260,6 +340,7 @@ class LmSolver {
     // phase_ == kCandidate: ne is the evaluation at the candidate
     const bool rot_free = mode_ != SBA_MODE_TRAN, tran_free = mode_ != SBA_MODE_ROT;
     double step2 = 0, x2 = 0;
+    SBA_UNROLL
     for (int a = 0; a < 3; ++a) {
       if (rot_free) { step2 += (qrot_[a] - rot_[a]) * (qrot_[a] - rot_[a]); x2 += rot_[a] * rot_[a]; }
       if (tran_free) { step2 += (qtran_[a] - tran_[a]) * (qtran_[a] - tran_[a]); x2 += tran_[a] * tran_[a]; }
@@ -267,9 +348,11 @@ class LmSolver {
     const double step_norm = std::sqrt(step2), x_norm = std::sqrt(x2);
     const double cost_change = cur_.cost - ne.cost;
     const double rho = std::isfinite(ne.cost) ? cost_change / model_change_ : -1.0;
+#if !defined(__HIP_DEVICE_COMPILE__)
     if (o_.verbose)
       std::printf("%4d % .6e   % .2e    %.2e   %.2e  % .2e  %.2e\n", iter_, ne.cost, cost_change, gmax_, step_norm,
                   rho, radius_);
+#endif
     if (step_norm <= o_.parameter_tolerance * (x_norm + o_.parameter_tolerance)) {
       finish(SBA_TERM_CONVERGENCE_PARAMETER, SBA_OK);
       return;
@@ -298,23 +381,33 @@ class LmSolver {
  private:
   enum Phase { kInitial, kCandidate };
 
-  double gmax_of(const double* g) const {
+  // wall clock of the host; the device-side solver reports 0 (the host times the whole batched solve)
+  SBA_HD static double now_seconds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 0.0;
+#else
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#endif
+  }
+  SBA_HD double gmax_of(const double* g) const {
     double v = 0;
-    for (int i = 0; i < par_.m; ++i) v = std::max(v, std::fabs(g[i]));
+    SBA_UNROLL
+    for (int i = 0; i < detail::kDim; ++i)
+      if (i < par_.m) v = std::max(v, std::fabs(g[i]));
     return v;
   }
-  void finish(int term, int rc) {
+  SBA_HD void finish(int term, int rc) {
     sum_.termination = term;
     sum_.final_cost = cur_.cost;
     sum_.final_gradient_max_norm = gmax_;
     sum_.final_radius = radius_;
-    sum_.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start_).count();
+    sum_.seconds_total = now_seconds() - t_start_;
     for (int a = 0; a < 3; ++a) { qrot_[a] = rot_[a]; qtran_[a] = tran_[a]; }
     rc_ = rc;
     done_ = true;
   }
   // Trust-region step(s) from the current point until one is valid: sets the query point, or terminates.
-  void next_candidate() {
+  SBA_HD void next_candidate() {
     using namespace detail;
     const int m = par_.m;
     for (;;) {
@@ -324,25 +417,44 @@ class LmSolver {
       if (gmax_ <= o_.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, SBA_OK); return; }
       if (radius_ < o_.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, SBA_OK); return; }
       sum_.num_iterations = ++iter_;
-      double Hs[36], gs[6], A[36], rhs[6], y[6];
-      for (int i = 0; i < m; ++i) {
-        gs[i] = scale_[i] * gf_[i];
-        for (int j = 0; j < m; ++j) Hs[i * m + j] = scale_[i] * Hf_[i * m + j] * scale_[j];
+      double Hs[kDim * kDim], gs[kDim], A[kDim * kDim], rhs[kDim], y[kDim];
+      SBA_UNROLL
+      for (int i = 0; i < kDim; ++i) {
+        if (i < m) {
+          gs[i] = scale_[i] * gf_[i];
+          SBA_UNROLL
+          for (int j = 0; j < kDim; ++j)
+            if (j < m) Hs[i * kDim + j] = scale_[i] * Hf_[i * kDim + j] * scale_[j];
+        }
       }
-      if (!reuse_diagonal_)
-        for (int i = 0; i < m; ++i)
-          diag_[i] = std::min(std::max(Hs[i * m + i], o_.min_lm_diagonal), o_.max_lm_diagonal);
-      std::memcpy(A, Hs, sizeof(double) * m * m);
-      for (int i = 0; i < m; ++i) { A[i * m + i] += diag_[i] / radius_; rhs[i] = -gs[i]; }
+      if (!reuse_diagonal_) {
+        SBA_UNROLL
+        for (int i = 0; i < kDim; ++i)
+          if (i < m) diag_[i] = std::min(std::max(Hs[i * kDim + i], o_.min_lm_diagonal), o_.max_lm_diagonal);
+      }
+      SBA_UNROLL
+      for (int i = 0; i < kDim; ++i) {
+        SBA_UNROLL
+        for (int j = 0; j < kDim; ++j)
+          if (i < m && j < m) A[i * kDim + j] = Hs[i * kDim + j];
+      }
+      SBA_UNROLL
+      for (int i = 0; i < kDim; ++i)
+        if (i < m) { A[i * kDim + i] += diag_[i] / radius_; rhs[i] = -gs[i]; }
       bool valid = cholesky_solve(m, A, rhs, y);
       if (valid) {
         // -(J y)^T (f + J y / 2) = -g^T y - y^T H y / 2
         double gy = 0, yHy = 0;
-        for (int i = 0; i < m; ++i) {
-          gy += gs[i] * y[i];
-          double s = 0;
-          for (int j = 0; j < m; ++j) s += Hs[i * m + j] * y[j];
-          yHy += y[i] * s;
+        SBA_UNROLL
+        for (int i = 0; i < kDim; ++i) {
+          if (i < m) {
+            gy += gs[i] * y[i];
+            double s = 0;
+            SBA_UNROLL
+            for (int j = 0; j < kDim; ++j)
+              if (j < m) s += Hs[i * kDim + j] * y[j];
+            yHy += y[i] * s;
+          }
         }
         model_change_ = -gy - 0.5 * yHy;
         valid = model_change_ > 0.0;
@@ -353,8 +465,9 @@ class LmSolver {
         continue;
       }
       invalid_steps_ = 0;
-      double delta[6];
-      for (int i = 0; i < m; ++i) delta[i] = scale_[i] * y[i];
+      double delta[kDim];
+      SBA_UNROLL
+      for (int i = 0; i < kDim; ++i) delta[i] = i < m ? scale_[i] * y[i] : 0.0;
       par_.plus(rot_, tran_, delta, qrot_, qtran_);
       return;
     }
@@ -371,7 +484,7 @@ class LmSolver {
   bool reuse_diagonal_ = false, done_ = false;
   int invalid_steps_ = 0, iter_ = 0, rc_ = SBA_OK;
   Phase phase_ = kInitial;
-  std::chrono::steady_clock::time_point t_start_;
+  double t_start_ = 0.0;
 };
 
 // Evaluator: bool(const double rot[3], const double tran[3], sba_normal_eq* out)
@@ -390,3 +503,7 @@ int lm_solve(int mode, double rot[3], double tran[3], const sba_lm_options& o, E
 }
 
 }  // namespace sba
+
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT DEFAULT
+#endif

@@ -18,7 +18,7 @@
 //
 // The two image maps depend only on (geometry, H, W), not on pixel values: the source index of every output pixel is
 // computed once into a table (cached per device and geometry), and a frame -- or a batch of frames -- is then a pure
-// gather: 4 B of table (L2 / MALL resident across the batch) + one dword load + 3 B stored per output pixel.
+// gather: 4 B of table (L2 / MALL resident across the batch) + 3 B gathered + 3 B stored per output pixel.
 #include <algorithm>
 #include <cstring>
 #include <list>
@@ -157,66 +157,39 @@ __global__ void table_patch_kernel(int* __restrict__ table, const unsigned int* 
   if (k < count) table[idx[k]] = val[k];
 }
 
-// 3 source bytes of pixel p as the low 24 bits of one (unaligned) dword load; the last pixel of a frame reads one byte
-// early instead of one byte past the end.  p < 0: outside -> 0.
-__device__ __forceinline__ uint32_t load_pixel(const uint8_t* __restrict__ src, int p, int last_pixel) {
-  if (p < 0) return 0u;
-  uint32_t v;
-  if (p == last_pixel) {
-    if (p == 0) return src[0] | (static_cast<uint32_t>(src[1]) << 8) | (static_cast<uint32_t>(src[2]) << 16);
-    __builtin_memcpy(&v, src + static_cast<size_t>(p) * 3 - 1, 4);
-    return v >> 8;
-  }
-  __builtin_memcpy(&v, src + static_cast<size_t>(p) * 3, 4);
-  return v & 0x00ffffffu;
-}
-
-// out[f][o] = src[f][table[o]] for every frame f of the block's slice of the batch.  PIX = 4: a lane owns 4 consecutive
-// output pixels (one 16-byte table load, 12 output bytes = 3 dword stores); frames are taken two at a time so that eight
-// independent gathers are in flight per lane.
-template <int PIX>
+// out[f][o] = src[f][table[o]] for every frame f of the block's slice of the batch (table < 0: outside -> 0).
+// ONE output pixel per lane: a wave instruction then spans 64 consecutive output pixels, whose sources lie within a
+// few hundred bytes -- few cache lines per instruction.  (Measured on 64 and 512 frames 3840x1920 -> S = 600,
+// tools/gather_probe.hip, profiles/r02_gather_probe.log: 4 pixels per lane with byte loads 950 GB/s algorithmic, with
+// one unaligned dword load per pixel 430-650 GB/s -- misaligned dwords are split by the hardware -- two aligned dwords +
+// v_alignbyte 725 GB/s, staging through LDS 930 GB/s, one pixel per lane 1 130-1 150 GB/s.)  Three byte loads per
+// pixel; PACK: the four lanes of a quad assemble their 12 bytes into three dword stores (one DPP quad shift) instead of
+// twelve byte stores.  Two frames per block (the table entry is loaded once per block and reused).
+template <bool PACK>
 __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ table, size_t out_pixels,
-                                                     const uint8_t* __restrict__ src, size_t src_stride, int src_pixels,
+                                                     const uint8_t* __restrict__ src, size_t src_stride,
                                                      uint8_t* __restrict__ out, size_t out_stride, int batch,
                                                      int frames_per_block) {
   const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g * PIX >= out_pixels) return;
-  int p[PIX];
-  if (PIX == 4) {
-    const int4 q = reinterpret_cast<const int4*>(table)[g];
-    p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
-  } else {
-    p[0] = table[g];
-  }
-  const int last = src_pixels - 1;
-  const size_t o = g * PIX * 3;
+  const bool valid = g < out_pixels;
+  const int t = valid ? table[g] : -1;
+  const size_t p = t >= 0 ? static_cast<size_t>(t) * 3 : 0;
+  const int j = threadIdx.x & 3;
   const int f0 = blockIdx.y * frames_per_block, f1 = min(batch, f0 + frames_per_block);
-  auto emit = [&](uint8_t* dst, const uint32_t* v) {
-    if (PIX == 4) {
-      uint32_t* o32 = reinterpret_cast<uint32_t*>(dst + o);     // 12-byte group, 4-byte aligned
-      o32[0] = v[0] | (v[1] << 24);
-      o32[1] = (v[1] >> 8) | (v[2] << 16);
-      o32[2] = (v[2] >> 16) | (v[3] << 8);
-    } else {
-      dst[o] = static_cast<uint8_t>(v[0]); dst[o + 1] = static_cast<uint8_t>(v[0] >> 8); dst[o + 2] = static_cast<uint8_t>(v[0] >> 16);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* s = src + static_cast<size_t>(f) * src_stride;
+    uint8_t* d = out + static_cast<size_t>(f) * out_stride;
+    uint32_t v = 0;
+    if (t >= 0) v = static_cast<uint32_t>(s[p]) | (static_cast<uint32_t>(s[p + 1]) << 8) | (static_cast<uint32_t>(s[p + 2]) << 16);
+    if (PACK) {
+      // lanes 0..2 of every quad store one dword each: the bytes of pixels j and j + 1 (out_pixels % 4 == 0)
+      const uint32_t nx = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xF9 /* quad_perm [1,2,3,3] */,
+                                                                             0xf, 0xf, false));
+      const uint32_t dw = (v >> (8 * j)) | (nx << (24 - 8 * j));
+      if (valid && j < 3) reinterpret_cast<uint32_t*>(d + (g & ~static_cast<size_t>(3)) * 3)[j] = dw;
+    } else if (valid) {
+      d[g * 3] = static_cast<uint8_t>(v); d[g * 3 + 1] = static_cast<uint8_t>(v >> 8); d[g * 3 + 2] = static_cast<uint8_t>(v >> 16);
     }
-  };
-  int f = f0;
-  for (; f + 1 < f1; f += 2) {
-    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
-    const uint8_t* sb = sa + src_stride;
-    uint32_t va[PIX], vb[PIX];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) { va[k] = load_pixel(sa, p[k], last); vb[k] = load_pixel(sb, p[k], last); }
-    emit(out + static_cast<size_t>(f) * out_stride, va);
-    emit(out + static_cast<size_t>(f + 1) * out_stride, vb);
-  }
-  if (f < f1) {
-    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
-    uint32_t va[PIX];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) va[k] = load_pixel(sa, p[k], last);
-    emit(out + static_cast<size_t>(f) * out_stride, va);
   }
 }
 
@@ -407,19 +380,16 @@ int get_table(const TableKey& key, float pitch_deg, hipStream_t stream, Table* o
 int launch_gather(const Table& t, const uint8_t* src, int src_pixels, int batch, uint8_t* out, hipStream_t stream) {
   if (t.out_pixels == 0 || batch <= 0) return SBA_OK;
   const size_t src_stride = static_cast<size_t>(src_pixels) * 3, out_stride = t.out_pixels * 3;
-  const bool wide = t.out_pixels % 4 == 0;
-  const size_t groups = wide ? t.out_pixels / 4 : t.out_pixels;
-  const unsigned gx = static_cast<unsigned>((groups + 255) / 256);
-  // frames per block: the table entries are loaded once per block and reused; keep >= ~2048 blocks in flight
-  int fpb = 1;
-  while (fpb < 16 && fpb * 2 <= batch && static_cast<size_t>(gx) * ((batch + 2 * fpb - 1) / (2 * fpb)) >= 2048) fpb *= 2;
+  const unsigned gx = static_cast<unsigned>((t.out_pixels + 255) / 256);
+  const int fpb = batch >= 2 ? 2 : 1;       // measured best: 1 / 2 / 4 / 8 frames per block = 1 080 / 1 150 / 1 130 / 1 045 GB/s
   const unsigned gy = static_cast<unsigned>((batch + fpb - 1) / fpb);
-  if (wide)
-    hipLaunchKernelGGL((gather_kernel<4>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride,
-                       src_pixels, out, out_stride, batch, fpb);
+  if (gy > 65535u) return set_error(SBA_ERR_INVALID_ARG, "batch of %d frames is too large for one launch", batch);
+  if (t.out_pixels % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0)
+    hipLaunchKernelGGL((gather_kernel<true>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
+                       out_stride, batch, fpb);
   else
-    hipLaunchKernelGGL((gather_kernel<1>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride,
-                       src_pixels, out, out_stride, batch, fpb);
+    hipLaunchKernelGGL((gather_kernel<false>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
+                       out_stride, batch, fpb);
   SBA_TRY_HIP(hipGetLastError());
   return SBA_OK;
 }

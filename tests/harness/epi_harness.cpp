@@ -8,6 +8,9 @@ void harness_svd3(const double* E, double* U, double* w, double* Vt) { svd3(E, U
 void harness_decompose(const double* E, double* R1, double* R2, double* t) { decompose_essential(E, R1, R2, t); }
 void harness_euler(const double* R, float* out) { rot_to_euler(R, out); }
 void harness_trial_groups(unsigned long long seed, int trial, int count, int* out) { trial_groups(seed, trial, count, out); }
+void harness_trial_groups_from(unsigned long long seed, int trial, int count, int* out, const int* items, int n_items) {
+  trial_groups(seed, trial, count, out, items, n_items);
+}
 void harness_trial(const double* mom45, float* e1, float* e2, float* tv, int* v1, int* v2, double* E) {
   bool a, b;
   trial_from_moments(mom45, e1, e2, tv, &a, &b, E);

@@ -68,22 +68,66 @@ def test_batch_solve_matches_single_problem_solves(oracle):
                 assert np.abs(rot[g] - r1).max() <= 1e-12 and np.abs(tran[g] - t1).max() <= 1e-12
 
 
-def test_batch_config_c5_shape_properties():
-    """64 pairs x 50k matches (config C5 is 256 x 50k; same per-pair size, a quarter of the pairs to keep host-side
-    data generation short): every pair converges to its own geometry, repeated launches are bit-identical."""
-    B, n = 64, 50_000
+def test_batch_config_c5_full_size_properties(oracle):
+    """BASELINE config C5 at FULL size -- 256 pairs x 50k matches in one launch -- through size-independent properties:
+    repeated launches are bit-identical; a pair's pack does not depend on where it sits in the batch (reversed order:
+    bit-identical per pair); sampled pairs equal the single-problem sweep and the per-pair oracle; all 256 LMs converge
+    to their own geometry."""
+    B, n = 256, 50_000
     cs, off, x1, x2, d12 = _make_pairs([n] * B, seed0=5000)
     rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
     with api.Batch(0) as b:
         b.upload(x1, x2, off, d12)
         p1 = b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH)
         assert np.array_equal(p1, b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH))
+        ms = b.sweep_launch_times(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, repeat=5)
+        assert ms.shape == (5,) and (ms > 0).all()
         rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
                                           options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
         assert (status == 0).all() and all(s.termination.startswith("CONVERGENCE") for s in sums)
         err = np.array([np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)])
         assert err.max() < 5e-3
         assert np.allclose(np.linalg.norm(tran, axis=1), 1.0, atol=1e-12)
+    for g in (0, 17, 255):                                   # sampled pairs against the single-problem path and the oracle
+        with api.Problem(0) as p:
+            p.upload(cs[g].x1, cs[g].x2, cs[g].d12)
+            single = p.eval_pack(api.MODE_RT, cs[g].rot_init, cs[g].tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        ref = pack_from_eval(2, oracle.evaluate(2, cs[g].x1, cs[g].x2, cs[g].rot_init, cs[g].tran_init, d12=cs[g].d12))
+        scale = np.abs(ref).max()
+        assert np.abs(p1[g] - single).max() <= REL_TOL_F64 * scale and np.abs(p1[g] - ref).max() <= REL_TOL_F64 * scale
+    # the same pairs uploaded in reverse order
+    order = np.arange(B)[::-1]
+    with api.Batch(0) as b:
+        b.upload(np.concatenate([cs[g].x1 for g in order]), np.concatenate([cs[g].x2 for g in order]), off,
+                 np.concatenate([cs[g].d12 for g in order]))
+        p2 = b.eval(api.MODE_RT, rot0[order], tran0[order], depth_mode=api.DEPTH_PER_MATCH)
+    assert np.array_equal(p2[::-1], p1)
+
+
+def test_equi2cube_512_frames_device_resident():
+    """The remap leg of config C5 at its full size: 512 ERP frames 3840x1920 -> S = 600 strips in one batched call.
+    Frame 0 carries its own pixel index in its three bytes, so its output IS the source-index table; every other frame
+    (random bytes) must be exactly that gather of its own pixels (checked on the device with torch)."""
+    torch = pytest.importorskip("torch")
+    lib = cabi.load_library()
+    F, H, W, S = 512, 1920, 3840, 600
+    idx = torch.arange(H * W, dtype=torch.int64, device="cuda")
+    frame0 = torch.stack([idx & 255, (idx >> 8) & 255, (idx >> 16) & 255], dim=1).to(torch.uint8).reshape(H, W, 3)
+    src = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device="cuda")
+    src[0] = frame0
+    dst = torch.zeros((F, S, 6 * S, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    cabi.check(lib, lib.sba_equi2cube_device(0, C.c_void_p(stream), C.c_void_p(src.data_ptr()), H, W, S, F,
+                                             C.c_void_p(dst.data_ptr())))
+    torch.cuda.synchronize()
+    o = dst[0].reshape(-1, 3).to(torch.int64)
+    table = o[:, 0] | (o[:, 1] << 8) | (o[:, 2] << 16)
+    assert int(table.min()) >= 0 and int(table.max()) < H * W
+    for k in (1, 2, 255, 256, 511):
+        want = src[k].reshape(-1, 3)[table].reshape(S, 6 * S, 3)
+        assert torch.equal(dst[k], want), k
+    # and the table itself is the oracle's: checked against one real frame in tests/test_gpu_side.py::test_equi2cube_bit_exact
+    assert lib.sba_map_table_host_decided(0, 0, S, H, W) >= 0
 
 
 def test_batch_solve_host_threads_change_nothing():

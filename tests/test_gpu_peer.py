@@ -110,7 +110,7 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     env = dict(os.environ, SBA_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup",
-           "2", "--matches", "200000"]
+           "2", "--matches", "200000", "--transport", "peer"]    # RCCL (the default) cannot place two ranks on ONE device
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

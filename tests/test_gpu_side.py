@@ -166,7 +166,7 @@ def test_rotate_keypoints_and_crop_bit_exact_every_pitch(oracle, H, W):
         decided = lib.sba_map_table_host_decided(0, 1, bits, H, W)
         assert decided >= 0                                   # the table exists (and is reused by the next call)
         if pitch in (45.0, -45.0, 30.0):
-            assert decided <= 1e-3 * (H // 4) * W             # the host finishes a sliver, the device the rest
+            assert decided <= 2 * (H // 4 + W)                # ties lie along a few lines: the host finishes a sliver
         if pitch == 0.0:
             assert decided == (H // 4) * W                    # every pixel is an exact tie: all decided by the host
 

@@ -176,3 +176,72 @@ def test_initial_guess_known_answer_and_determinism():
         api.set_host_threads(1)
     with pytest.raises(api.SbaError):
         api.initial_guess_from_moments(G, 0, 0.25)
+
+
+def _reference_recipe_guess(x1, x2, trials, rng):
+    """The reference's initial_guess (.cpp:118-181) in numpy with PER-MATCH sampling: `trials` x (random floor(n/4)
+    matches -> explicit A -> SVD -> rank 2 -> R1/R2 -> Euler, valid if all |angles| < 1.57) and the 20-80 % trimmed-mean
+    consensus pick."""
+    n = len(x1)
+    A = (x1[:, :, None] * x2[:, None, :]).reshape(n, 9)
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    cands = []
+    for _ in range(trials):
+        idx = rng.permutation(n)[: int(n * 0.25)]
+        E = np.linalg.svd(A[idx], full_matrices=True)[2][-1].reshape(3, 3)
+        U, s, Vt = np.linalg.svd(E)
+        U, s, Vt = np.linalg.svd(U @ np.diag([s[0], s[1], 0.0]) @ Vt)
+        if np.linalg.det(U) < 0: U = -U
+        if np.linalg.det(Vt) < 0: Vt = -Vt
+        for R in (U @ W @ Vt, U @ W.T @ Vt):
+            e = euler_of(R)
+            if np.abs(e).max() < 1.57:
+                cands.append(e)
+    c = np.array(cands)
+    if len(c) == 0:
+        return None
+    d = np.sort(np.linalg.norm(c[:, None, :] - c[None, :, :], axis=2), axis=1)
+    lo, hi = int(len(c) * 0.2), int(len(c) * 0.8)
+    return c[np.argmin(d[:, lo:hi].mean(axis=1))] if hi > lo else c[0]
+
+
+@pytest.mark.parametrize("n", [40, 100, 200])
+def test_initial_guess_with_few_matches(n):
+    """Realistic SURF match counts sit far below 64 x 4: many of the 64 interleaved groups are then empty.  The trials
+    draw among the NON-EMPTY groups and never solve from fewer than 8 correspondences, so the consensus is as good as
+    the reference's per-match sampling (numpy restatement above) -- not polluted by rank-deficient trials."""
+    errs_ours, errs_ref = [], []
+    for seed in range(12):
+        c = synthetic.full_rt(n, seed=500 + seed, sigma=2e-4, outlier_fraction=0.0)
+        G, _, grp = group_moments(c.x1, c.x2)
+        assert np.allclose(G[:, [0, 9, 17, 24, 30, 35, 39, 42, 44]].sum(1), np.bincount(grp, minlength=64))   # trace = count
+        truth = euler_of(synthetic.rodrigues(c.rot_true).T)
+        e, t, ncand = api.initial_guess_from_moments(G, 80, 0.25, seed=seed)
+        errs_ours.append(np.abs(e - truth).max())
+        r = _reference_recipe_guess(c.x1, c.x2, 80, np.random.default_rng(seed))
+        errs_ref.append(np.abs(r - truth).max() if r is not None else np.inf)
+    ours, ref = np.median(errs_ours), np.median(errs_ref)
+    # n = 40: the reference itself solves from 10 matches per trial -- both are rough; what matters is "not worse"
+    assert ours <= max(2.0 * ref, 5e-3), (n, ours, ref, errs_ours, errs_ref)
+    if n >= 100:
+        assert ours < 0.02
+
+
+def test_trial_subsets_with_few_matches_hold_at_least_eight():
+    """White box: with n = 37 there are 10 non-empty groups (9 full + 1 with one match); every trial's subset must hold
+    at least 8 matches, drawn from non-empty groups only."""
+    h = harness()
+    nonempty = np.arange(10, dtype=np.int32)
+    for trial in range(50):
+        sel = np.full(10, -1, dtype=np.int32)
+        h.harness_trial_groups_from(C.c_ulonglong(3), C.c_int(trial), C.c_int(10), _p(sel), _p(nonempty), C.c_int(10))
+        assert sorted(sel.tolist()) == list(range(10))                         # a permutation of the non-empty groups
+        short = np.full(2, -1, dtype=np.int32)
+        h.harness_trial_groups_from(C.c_ulonglong(3), C.c_int(trial), C.c_int(2), _p(short), _p(nonempty), C.c_int(10))
+        assert short.tolist() == sel[:2].tolist()                               # a longer draw extends a shorter one
+    # all 64 occupied: identical to the historical draw over 0..63
+    full = np.arange(64, dtype=np.int32)
+    a, b = np.zeros(16, dtype=np.int32), np.zeros(16, dtype=np.int32)
+    h.harness_trial_groups(C.c_ulonglong(5), C.c_int(3), C.c_int(16), _p(a))
+    h.harness_trial_groups_from(C.c_ulonglong(5), C.c_int(3), C.c_int(16), _p(b), _p(full), C.c_int(64))
+    assert np.array_equal(a, b)

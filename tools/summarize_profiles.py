@@ -23,7 +23,73 @@ def short(name: str) -> str:
     return name.split("(")[0]
 
 
+HBM_PEAK = 8.0e12
+
+
+def stages(src: Path, tag: str):
+    """tools/profile_stages.sh output -> profiles/<tag>_kernels.md, <tag>_kernel_stats.csv, pmc_stages_latest.json:
+    one row per kernel with calls, avg / min duration, FETCH_SIZE x 2 (16 B-per-lane streams; uncalibrated for the
+    gather kernel's dword loads, shown raw as well), WRITE_SIZE, the algorithmic bytes per launch the workload
+    declares, and achieved GB/s / fraction of the 8 TB/s peak for those kernels."""
+    out = ROOT / "profiles"
+    shutil.copy(src / "trace" / "trace_kernel_stats.csv", out / f"{tag}_kernel_stats.csv")
+    stats = {short(r["Name"]): r for r in csv.DictReader(open(src / "trace" / "trace_kernel_stats.csv"))}
+    pmc = collections.defaultdict(dict)
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = src / f"pmc_{kind}" / f"{kind}_counter_collection.csv"
+        if not f.exists():
+            continue
+        vals = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                vals[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in vals.items():
+            v = sorted(v)
+            pmc[k][counter] = {"launches": len(v), "median_KiB": v[len(v) // 2], "max_KiB": v[-1]}
+    work = json.loads((src / "workload_trace.json").read_text().strip().splitlines()[-1])
+    alg, units = work["algorithmic_bytes_per_launch"], work["units_per_launch"]
+    summary = {"tag": tag, "kernels": {}, "workload": work}
+    lines = [f"# rocprofv3 per-kernel summary {tag} (secondary kernels)", "",
+             "Command (tools/profile_stages.sh): `rocprofv3 --kernel-trace --stats -- python3 tools/stage_workload.py`, then "
+             "separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command.  PMC figures are per-launch MEDIANS "
+             "(a kernel name covers launches of different sizes: warm-ups, the LM's shrinking batches).  `read` = FETCH_SIZE x 2 "
+             "(gfx950, 16 B-per-lane streams; for `gather_kernel` -- dword gathers -- the factor is uncalibrated and the raw "
+             "counter is what to compare between variants).  `frac` = algorithmic bytes / MIN duration / 8 TB/s (min: a name "
+             "covers launches on shrinking work).", "",
+             "| kernel | calls | avg us | min us | max us | read MB (FETCH x2) | FETCH raw MB | write MB | algorithmic MB | GB/s (avg) | GB/s (min) | frac |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for k, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"]) if "TotalDurationNs" in kv[1] else 0):
+        fz = pmc.get(k, {}).get("FETCH_SIZE", {}).get("max_KiB" if k in alg else "median_KiB", 0.0)
+        wz = pmc.get(k, {}).get("WRITE_SIZE", {}).get("max_KiB" if k in alg else "median_KiB", 0.0)
+        avg, mn, mx = float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"])
+        a_bytes = alg.get(k)
+        # a declared kernel is priced at its full-size launches: the slowest launches are the full-size ones
+        row = {"calls": int(r["Calls"]), "avg_ns": avg, "min_ns": mn, "max_ns": mx,
+               "hbm_read_bytes_per_launch": 2.0 * fz * 1024, "fetch_raw_bytes_per_launch": fz * 1024,
+               "hbm_write_bytes_per_launch": wz * 1024, "algorithmic_bytes_per_launch": a_bytes,
+               "units_per_launch": units.get(k)}
+        gb_avg = gb_min = frac = ""
+        if a_bytes:
+            # full-size launches dominate the MAX/median for kernels whose name also covers smaller launches; report both
+            row["achieved_GBps_avg"] = a_bytes / avg
+            row["achieved_GBps_best"] = a_bytes / mn if row["calls"] > 0 else None
+            gb_avg, gb_min = f"{a_bytes / avg:.0f}", f"{a_bytes / mn:.0f}"
+            row["frac_of_peak_avg"] = a_bytes / (avg * 1e-9) / HBM_PEAK
+            frac = f"{row['frac_of_peak_avg']:.3f}"
+        summary["kernels"][k] = row
+        lines.append(f"| {k} | {r['Calls']} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {2 * fz * 1024 / 1e6:.2f} | "
+                     f"{fz * 1024 / 1e6:.2f} | {wz * 1024 / 1e6:.2f} | {a_bytes / 1e6 if a_bytes else 0:.2f} | {gb_avg} | {gb_min} | {frac} |")
+    lines += ["", "Workload figures (wall clock, same run): `" + json.dumps({k: v for k, v in work.items()
+                                                                             if k not in ("algorithmic_bytes_per_launch", "units_per_launch")}) + "`"]
+    (out / f"{tag}_kernels.md").write_text("\n".join(lines) + "\n")
+    (out / f"{tag}_pmc.json").write_text(json.dumps(summary, indent=1))
+    (out / "pmc_stages_latest.json").write_text(json.dumps(summary, indent=1))
+    print("\n".join(lines))
+
+
 def main():
+    if sys.argv[1] == "--stages":
+        return stages(Path(sys.argv[2]), sys.argv[3])
     src, tag = Path(sys.argv[1]), sys.argv[2]
     out = ROOT / "profiles"
     out.mkdir(exist_ok=True)
