@@ -323,7 +323,7 @@ int sba_set_host_threads(int n);
 
 /* ---- 8-point initial guess (eight_point_estimation / initial_guess, spherical_bundle_adjuster.cpp:47-181) ---- */
 /* Device part: one pass over the uploaded correspondences accumulating A^T A of the rows kron(left_i, right_i)
- * (.cpp:53-68) for 64 interleaved groups, group(i) = (i / 4) % 64.  groups: double[64][45] (upper triangle,
+ * (.cpp:53-68) for 64 interleaved groups, group(i) = (i / 2) % 64.  groups: double[64][45] (upper triangle,
  * row-major a <= b).  With a transport attached (sharded problem) the sums are all-reduced: every rank receives
  * the moments of the whole problem (group g = the union of all shards' group g) and so derives the same guess.  */
 int sba_problem_epipolar_moments(sba_problem* p, double* groups);

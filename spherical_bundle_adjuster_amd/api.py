@@ -244,7 +244,7 @@ class Problem:
 
     # -- 8-point initial guess ----------------------------------------------------------------------
     def epipolar_moments(self) -> np.ndarray:
-        """(64, 45): upper triangle of A^T A of the kron(left, right) rows per interleaved group (i//4) % 64."""
+        """(64, 45): upper triangle of A^T A of the kron(left, right) rows per interleaved group (i//2) % 64."""
         g = np.zeros((64, 45))
         cabi.check(self._lib, self._lib.sba_problem_epipolar_moments(self._h, _dptr(g)))
         return g

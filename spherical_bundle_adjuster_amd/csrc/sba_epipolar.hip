@@ -1,8 +1,10 @@
 // Device pass of the 8-point initial guess (reference spherical_bundle_adjuster.cpp:53-68: one row
 // kron(left_i, right_i) of the N x 9 matrix A per match).  Instead of materialising A for 80 random subsets and
 // running 80 SVDs of (N/4) x 9 matrices, one sweep accumulates A^T A separately for 64 interleaved groups of matches,
-// group(i) = (i / 4) % 64: a lane always handles 4 consecutive matches and keeps its own accumulators, so lane id ==
-// group id and no cross-lane reduction is needed at all.
+// group(i) = (i / 2) % 64: a lane always handles 2 consecutive matches -- ONE 16-byte vector of each f64 plane, so every
+// wave load instruction covers 1 KiB contiguous like the sweep kernel's -- and keeps its own accumulators, so lane id ==
+// group id and no cross-lane reduction is needed at all.  (Round 1 grouped by 4 matches: two 16-byte loads per lane at
+// a 32-byte lane stride, i.e. every load instruction touched twice the cache lines it used; 5.0-5.4 TB/s.)
 //
 // Kronecker structure: entry ((p,q),(r,s)) of A^T A is sum l_p r_q l_r r_s = sum P_pr Q_qs with P = l l^T, Q = r r^T
 // symmetric -- only 6 x 6 = 36 DISTINCT sums (the 45 entries of the upper triangle repeat 9 of them).  36 accumulators
@@ -43,20 +45,20 @@ constexpr EntryMap make_entry_map() {
 }
 __constant__ EntryMap kEntryMap = make_entry_map();
 
+// two consecutive matches of one plane
 template <typename ST>
-__device__ __forceinline__ void load4(const void* plane, size_t quad, double out[4]);
+__device__ __forceinline__ void load2(const void* plane, size_t vec, double out[2]);
 template <>
-__device__ __forceinline__ void load4<double>(const void* plane, size_t quad, double out[4]) {
+__device__ __forceinline__ void load2<double>(const void* plane, size_t vec, double out[2]) {
   typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 ra = __builtin_nontemporal_load(reinterpret_cast<const f4*>(plane) + 2 * quad);
-  const f4 rb = __builtin_nontemporal_load(reinterpret_cast<const f4*>(plane) + 2 * quad + 1);
-  const double2 a = *reinterpret_cast<const double2*>(&ra), b = *reinterpret_cast<const double2*>(&rb);
-  out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+  const f4 r = __builtin_nontemporal_load(reinterpret_cast<const f4*>(plane) + vec);
+  const double2 a = *reinterpret_cast<const double2*>(&r);
+  out[0] = a.x; out[1] = a.y;
 }
 template <>
-__device__ __forceinline__ void load4<float>(const void* plane, size_t quad, double out[4]) {
-  const float4 a = reinterpret_cast<const float4*>(plane)[quad];
-  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+__device__ __forceinline__ void load2<float>(const void* plane, size_t vec, double out[2]) {
+  const float2 a = reinterpret_cast<const float2*>(plane)[vec];
+  out[0] = a.x; out[1] = a.y;
 }
 
 // partials[block][sum][lane]  (sum-major so that the 64 lanes store 512 contiguous bytes per sum)
@@ -68,31 +70,35 @@ __global__ __launch_bounds__(256) void epipolar_moments_kernel(Planes pl, unsign
 #pragma unroll
   for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t nquad = (n + 3) / 4;
+  const size_t nvec = (n + 1) / 2;
   const size_t stride = static_cast<size_t>(gridDim.x) * 256;
-  // quad index = 64 * (something) + lane, so group(quad) = quad % 64 = lane for every wave of every block.
-  // Next quad's loads are issued before the current one is consumed (register double buffer, like the sweep kernel).
+  // vector index = 64 * (something) + lane, so group(vector) = vector % 64 = lane for every wave of every block.
+  // Two vectors ahead are in flight before the current one is consumed (register double buffer, like the sweep kernel).
   size_t q = (static_cast<size_t>(blockIdx.x) * 4 + wave) * 64 + lane;
-  double cur[6][4], nxt[6][4];
-  if (q < nquad) {
+  double cur[6][2], nx1[6][2], nx2[6][2];
+  if (q < nvec) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { load4<ST>(pl.x1[k], q, cur[k]); load4<ST>(pl.x2[k], q, cur[3 + k]); }
+    for (int k = 0; k < 3; ++k) { load2<ST>(pl.x1[k], q, cur[k]); load2<ST>(pl.x2[k], q, cur[3 + k]); }
   }
-  while (q < nquad) {
-    const size_t qn = q + stride;
-    if (qn < nquad) {
+  if (q + stride < nvec) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { load4<ST>(pl.x1[k], qn, nxt[k]); load4<ST>(pl.x2[k], qn, nxt[3 + k]); }
+    for (int k = 0; k < 3; ++k) { load2<ST>(pl.x1[k], q + stride, nx1[k]); load2<ST>(pl.x2[k], q + stride, nx1[3 + k]); }
+  }
+  while (q < nvec) {
+    const size_t q2 = q + 2 * stride;
+    if (q2 < nvec) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { load2<ST>(pl.x1[k], q2, nx2[k]); load2<ST>(pl.x2[k], q2, nx2[3 + k]); }
     }
 #pragma unroll
-    for (int h = 0; h < 4; ++h)
-      if (4 * q + h < n)   // the planes are zero-padded, so this only guards the count-exactness of a ragged tail
+    for (int h = 0; h < 2; ++h)
+      if (2 * q + h < n)   // the planes are zero-padded, so this only guards the count-exactness of a ragged tail
         add_match(cur[0][h], cur[1][h], cur[2][h], cur[3][h], cur[4][h], cur[5][h], acc);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
-      for (int h = 0; h < 4; ++h) cur[k][h] = nxt[k][h];
-    q = qn;
+      for (int h = 0; h < 2; ++h) { cur[k][h] = nx1[k][h]; nx1[k][h] = nx2[k][h]; }
+    q += stride;
   }
   // waves 2,3 -> LDS; waves 0,1 add them; wave 1 -> LDS; wave 0 adds and stores the block's row: a fixed order
   if (wave >= 2) {

@@ -8,7 +8,7 @@
 // 1.57 (.cpp:101-115); the candidate closest to the others in the 20-80 % trimmed-mean sense wins (.cpp:162-180).
 //
 // Here the O(N) part is one device pass (sba_epipolar.hip) that accumulates A^T A separately for 64 interleaved
-// groups of matches (group = (index / 4) % 64); a trial's subset is the union of a random quarter of the groups, so
+// groups of matches (group = (index / 2) % 64); a trial's subset is the union of a random quarter of the groups, so
 // its A^T A is a sum of 16 small matrices and the null vector of A is the eigenvector of the smallest eigenvalue of
 // A^T A.  Sampling whole groups instead of single matches is the documented deviation (the reference's own
 // sampling cannot be reproduced across C libraries anyway); everything after the null vector follows the reference
@@ -24,7 +24,7 @@
 namespace sba {
 namespace epi {
 
-constexpr int kGroups = 64;     // interleaved groups of matches: group(i) = (i / 4) % 64
+constexpr int kGroups = 64;     // interleaved groups of matches: group(i) = (i / 2) % 64
 constexpr int kMom = 45;        // upper triangle of the 9x9 A^T A
 
 // ---- cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9) -------------------------------

@@ -20,6 +20,7 @@
 // computed once into a table (cached per device and geometry), and a frame -- or a batch of frames -- is then a pure
 // gather: 4 B of table (L2 / MALL resident across the batch) + 3 B gathered + 3 B stored per output pixel.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <mutex>
@@ -165,17 +166,32 @@ __global__ void table_patch_kernel(int* __restrict__ table, const unsigned int* 
 // v_alignbyte 725 GB/s, staging through LDS 930 GB/s, one pixel per lane 1 130-1 150 GB/s.)  Three byte loads per
 // pixel; PACK: the four lanes of a quad assemble their 12 bytes into three dword stores (one DPP quad shift) instead of
 // twelve byte stores.  Two frames per block (the table entry is loaded once per block and reused).
+//
+// Block -> work mapping (1-D grid): blocks are dealt to the 8 XCDs round-robin and every XCD has its own L2, so
+// physical block b is given logical work item (b % 8) * ceil(total / 8) + b / 8: each XCD walks a CONTIGUOUS run of
+// (frame slice, pixel block) items -- whole frames, row after row -- and the source lines that neighbouring output rows
+// share are fetched into one L2 instead of up to eight (xcd_aware = 0: plain order, for A/B measurements).
 template <bool PACK>
 __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ table, size_t out_pixels,
                                                      const uint8_t* __restrict__ src, size_t src_stride,
                                                      uint8_t* __restrict__ out, size_t out_stride, int batch,
-                                                     int frames_per_block) {
-  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+                                                     int frames_per_block, unsigned blocks_x, unsigned total_items,
+                                                     int xcd_aware) {
+  unsigned item = blockIdx.x;
+  if (xcd_aware) {
+    const unsigned per = (total_items + 7u) / 8u;
+    item = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || item >= total_items) return;
+  } else if (item >= total_items) {
+    return;
+  }
+  const unsigned bx = item % blocks_x, by = item / blocks_x;
+  const size_t g = static_cast<size_t>(bx) * blockDim.x + threadIdx.x;
   const bool valid = g < out_pixels;
   const int t = valid ? table[g] : -1;
   const size_t p = t >= 0 ? static_cast<size_t>(t) * 3 : 0;
   const int j = threadIdx.x & 3;
-  const int f0 = blockIdx.y * frames_per_block, f1 = min(batch, f0 + frames_per_block);
+  const int f0 = static_cast<int>(by) * frames_per_block, f1 = min(batch, f0 + frames_per_block);
   for (int f = f0; f < f1; ++f) {
     const uint8_t* s = src + static_cast<size_t>(f) * src_stride;
     uint8_t* d = out + static_cast<size_t>(f) * out_stride;
@@ -383,13 +399,16 @@ int launch_gather(const Table& t, const uint8_t* src, int src_pixels, int batch,
   const unsigned gx = static_cast<unsigned>((t.out_pixels + 255) / 256);
   const int fpb = batch >= 2 ? 2 : 1;       // measured best: 1 / 2 / 4 / 8 frames per block = 1 080 / 1 150 / 1 130 / 1 045 GB/s
   const unsigned gy = static_cast<unsigned>((batch + fpb - 1) / fpb);
-  if (gy > 65535u) return set_error(SBA_ERR_INVALID_ARG, "batch of %d frames is too large for one launch", batch);
+  const unsigned long long total = static_cast<unsigned long long>(gx) * gy;
+  if (total > 0x7fffff00ull) return set_error(SBA_ERR_INVALID_ARG, "batch of %d frames is too large for one launch", batch);
+  static const int xcd_aware = [] { const char* e = std::getenv("SBA_GATHER_XCD"); return e && e[0] == '0' ? 0 : 1; }();
+  const unsigned grid = static_cast<unsigned>((total + 7ull) / 8ull * 8ull);     // whole rounds of the 8 XCDs
   if (t.out_pixels % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0)
-    hipLaunchKernelGGL((gather_kernel<true>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
-                       out_stride, batch, fpb);
+    hipLaunchKernelGGL((gather_kernel<true>), dim3(grid), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
+                       out_stride, batch, fpb, gx, static_cast<unsigned>(total), xcd_aware);
   else
-    hipLaunchKernelGGL((gather_kernel<false>), dim3(gx, gy), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
-                       out_stride, batch, fpb);
+    hipLaunchKernelGGL((gather_kernel<false>), dim3(grid), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
+                       out_stride, batch, fpb, gx, static_cast<unsigned>(total), xcd_aware);
   SBA_TRY_HIP(hipGetLastError());
   return SBA_OK;
 }

@@ -205,9 +205,9 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
   if (!p || !groups) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
   if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   SBA_TRY_HIP(hipSetDevice(p->device));
-  const size_t nquad = (p->n + 3) / 4;
-  // 256-thread blocks (4 waves x 64 quads), two resident per CU (the ~170-VGPR accumulator set allows 2 waves per SIMD)
-  const int grid = static_cast<int>(std::min<size_t>((nquad + 255) / 256, static_cast<size_t>(p->num_cus) * 2));
+  const size_t nvec = (p->n + 1) / 2;
+  // 256-thread blocks (4 waves x 64 vectors of 2 matches), two resident per CU
+  const int grid = static_cast<int>(std::min<size_t>((nvec + 255) / 256, static_cast<size_t>(p->num_cus) * 2));
   const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
   // scratch (block partials + the groups) lives in the handle: allocating 23 MB per call cost more than the pass
   const size_t need = (static_cast<size_t>(std::max(grid, 1)) + 1) * gsz;

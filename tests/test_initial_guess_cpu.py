@@ -30,10 +30,10 @@ def _p(a):
 
 
 def group_moments(x1, x2):
-    """numpy reference of the device pass: per group (i//4) % 64 the upper triangle of A^T A, A rows = kron(l, r)."""
+    """numpy reference of the device pass: per group (i//2) % 64 the upper triangle of A^T A, A rows = kron(l, r)."""
     n = len(x1)
     A = (x1[:, :, None] * x2[:, None, :]).reshape(n, 9)            # .cpp:59-67
-    grp = (np.arange(n) // 4) % 64
+    grp = (np.arange(n) // 2) % 64
     iu = np.triu_indices(9)
     out = np.zeros((64, 45))
     for g in range(64):
@@ -228,8 +228,8 @@ def test_initial_guess_with_few_matches(n):
 
 
 def test_trial_subsets_with_few_matches_hold_at_least_eight():
-    """White box: with n = 37 there are 10 non-empty groups (9 full + 1 with one match); every trial's subset must hold
-    at least 8 matches, drawn from non-empty groups only."""
+    """White box: with n = 19 there are 10 non-empty groups (9 full pairs + 1 with one match); every trial's subset
+    must hold at least 8 matches, drawn from non-empty groups only."""
     h = harness()
     nonempty = np.arange(10, dtype=np.int32)
     for trial in range(50):

@@ -296,3 +296,22 @@ def test_timed_cpu_baseline_variant_matches_checker(oracle):
         b = oracle.evaluate_f64(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12)
         assert np.abs(a.H - b.H).max() <= 1e-12 * np.abs(a.H).max() and abs(a.cost - b.cost) <= 1e-12 * a.cost
         assert np.abs(a.g - b.g).max() <= 1e-11 * max(np.abs(a.g).max(), 1e-300) and a.n_outlier == b.n_outlier
+
+
+@pytest.mark.parametrize("mode,n,seed", [(0, 400, 31), (1, 400, 32), (2, 400, 33), (2, 150, 34), (0, 60, 35)])
+def test_lm_trajectory_vs_independent_numpy_restatement(oracle, mode, n, seed):
+    """The oracle's LM loop against a numpy restatement written from Ceres' documented schedule with an independent
+    Jacobian (closed form) and numpy.linalg.solve: same termination, iteration and accepted-step counts, R|t to 1e-9.
+    (The product's host LM is held against the oracle iterate for iterate in tests/test_host_lm_cpu.py; this test is what
+    keeps that pair from being twins that agree with each other and with nothing else.)"""
+    import ref_lm_numpy as rl
+    gen = synthetic.full_rt if mode else synthetic.rotation_only
+    c = gen(n, seed=seed)
+    d12 = c.d12 if mode else None
+    r_o, t_o, s_o, rc = oracle.lm_solve(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=d12)
+    assert rc == 0
+    r_n, t_n, info = rl.solve(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=d12)
+    term = {1: "function", 2: "gradient", 3: "parameter", 4: "no_convergence", 5: "min_radius"}[s_o.termination]
+    assert (term, s_o.num_iterations, s_o.num_successful_steps) == (info["termination"], info["iterations"], info["successful"])
+    assert np.abs(r_o - r_n).max() <= 1e-9 and np.abs(t_o - t_n).max() <= 1e-9
+    assert abs(s_o.final_cost - info["cost"]) <= 1e-10 * info["cost"] and abs(s_o.initial_cost - info["initial_cost"]) <= 1e-10 * info["initial_cost"]

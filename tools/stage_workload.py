@@ -86,6 +86,6 @@ if a.frames > 0:
     out["equi2cube"] = {"frames": F, "ms_per_batch": ms, "frames_per_s": F / (ms * 1e-3),
                         "algorithmic_GBps": F * S * 6 * S * 6 / (ms * 1e-3) / 1e9,
                         "host_decided_table_entries": int(lib.sba_map_table_host_decided(0, 0, S, H, W))}
-    out["algorithmic_bytes_per_launch"]["gather_kernel<4>"] = F * S * 6 * S * 6
-    out["units_per_launch"]["gather_kernel<4>"] = F * S * 6 * S
+    out["algorithmic_bytes_per_launch"]["gather_kernel<true>"] = F * S * 6 * S * 6
+    out["units_per_launch"]["gather_kernel<true>"] = F * S * 6 * S
 print(json.dumps(out))
