@@ -79,8 +79,53 @@ def solves():
     np.savez(OUT / "solves.npz", **out)
 
 
+def depth_stage():
+    """d-only stage (reference .cpp:1004-1063) with Ceres' projected line search: starts whose full step fails Armijo,
+    a start where it never does, and the same without the line search (what round 1 computed)."""
+    out = {}
+    cases = [("ls_d1", 500, 6, 1.0, 1.0, 1.0), ("ls_d005", 400, 9, 0.05, 1.0, 1.0), ("ls_reg", 64, 23, 0.01, 20.0, 4.0),
+             ("plain_d2", 300, 12, 2.0, 1.0, 1.0)]
+    for name, n, seed, d0, lam, c_ in cases:
+        c = synthetic.full_rt(n, seed=seed)
+        out[f"{name}_x1"], out[f"{name}_x2"], out[f"{name}_rot"], out[f"{name}_tran"] = c.x1, c.x2, c.rot_init, c.tran_init
+        out[f"{name}_cfg"] = np.array([d0, lam, c_])
+        for tag, ls in (("ceres", 20), ("nols", 0)):
+            d, s, rc = orc.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, np.full((n, 2), d0), lam=lam, c=c_,
+                                       options=orc.default_options(max_num_line_search_step_size_iterations=ls))
+            assert rc == 0
+            out[f"{name}_{tag}_d"] = d
+            out[f"{name}_{tag}_meta"] = np.array([s.termination, s.num_iterations, s.num_successful_steps,
+                                                   s.num_line_search_steps, s.final_cost])
+    np.savez(OUT / "depth_stage.npz", **out)
+
+
+def maps():
+    """Integer / float32 coordinate maps of the matchers (spherical_surf.cpp:48-123, equi2cube_surf.cpp:19-76,
+    equi2cube.cpp:12-302) on a small geometry, every pitch the reference uses plus the all-ties pitch 0."""
+    rng = np.random.default_rng(77)
+    H, W, S = 96, 192, 24
+    im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    rr, cc = np.meshgrid(np.arange(H // 4), np.arange(W), indexing="ij")
+    kp = np.zeros((rr.size, 7), dtype=np.float32)
+    kp[:, 0], kp[:, 1] = cc.ravel(), rr.ravel()
+    out = dict(im=im, kp=kp, geometry=np.array([H, W, S]))
+    for pitch in (45.0, -45.0, -90.0, 0.0):
+        tag = f"p{int(pitch)}".replace("-", "m")
+        out[f"rotate_{tag}"] = orc.rotate_keypoints(kp, pitch, W, H)[:, :2]
+        out[f"crop_{tag}"] = orc.crop_rotated_image(im, pitch)
+    cube = np.zeros((400, 7), dtype=np.float32)
+    cube[:, 0] = rng.uniform(0, 6 * S, 400); cube[:, 1] = rng.uniform(0, S, 400)
+    cube[:6, 0] = [S / 2 + k * S for k in range(6)]; cube[:6, 1] = S / 2
+    out["cube_kp"] = cube
+    out["cube2equi"] = orc.cube2equi_keypoints(cube, S, W, H)[:, :2]
+    out["equi2cube"], _ = orc.equi2cube(im, S)
+    np.savez_compressed(OUT / "maps.npz", **out)
+
+
 if __name__ == "__main__":
     pointwise()
     reductions()
     solves()
+    depth_stage()
+    maps()
     print("golden fixtures written to", OUT)

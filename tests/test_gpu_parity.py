@@ -275,6 +275,25 @@ def test_depth_stage_line_search_matches_oracle(oracle, n, seed, d0, lam, c, ls)
     assert abs(s.final_cost - sref.final_cost) <= 1e-10 * sref.final_cost
 
 
+def test_depth_stage_golden_fixtures():
+    """The HIP d-only stage against the COMMITTED fixtures (tests/golden/depth_stage.npz: Ceres' default and the
+    no-line-search variant): counts equal, depths to 1e-7 of the largest depth."""
+    z = np.load(GOLDEN / "depth_stage.npz", allow_pickle=False)
+    for name in ("ls_d1", "ls_d005", "ls_reg", "plain_d2"):
+        d0, lam, c_ = (float(v) for v in z[f"{name}_cfg"])
+        n = len(z[f"{name}_x1"])
+        for tag, ls in (("ceres", 20), ("nols", 0)):
+            with api.Problem(0) as p:
+                p.upload(z[f"{name}_x1"], z[f"{name}_x2"], np.full((n, 2), d0))
+                d, s = p.solve_depths(z[f"{name}_rot"], z[f"{name}_tran"], lam=lam, c=c_,
+                                      options=api.default_lm_options(max_num_line_search_step_size_iterations=ls))
+            meta = z[f"{name}_{tag}_meta"]
+            assert (s.num_iterations, s.num_successful_steps, s.num_line_search_steps) == tuple(int(v) for v in meta[1:4]), (name, tag)
+            ref = z[f"{name}_{tag}_d"]
+            assert np.abs(d - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (name, tag)
+            assert abs(s.final_cost - meta[4]) <= 1e-10 * meta[4]
+
+
 def test_depth_stage_line_search_failure_keeps_full_step(oracle):
     """A search that cannot succeed (sufficient decrease 1 - 1e-12 can only be met by an exactly linear cost) leaves the
     step unscaled after the allowed contractions, like Ceres (`if (line_search_summary.success) delta *= ...`): the

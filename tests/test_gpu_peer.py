@@ -22,6 +22,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
+    import numpy as np
     from spherical_bundle_adjuster_amd import api as A, distributed, synthetic as syn
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,12 +38,19 @@ def _worker(rank, world, port, q):
             tr, _, _ = p.solve(A.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
             # d-only stage on the sharded problem: six global reductions exchanged per pass, identical step logic
             d, sd = p.solve_depths(c.rot_true, c.tran_true)
+            # ... and from a start whose full step fails Armijo: the line search's contraction passes are sharded too
+            p.set_depths(np.ones((hi - lo, 2)))
+            d_ls, sd_ls = p.solve_depths(c.rot_init, c.tran_init)
+            p.set_depths(d)
             # 8-point initial guess on the sharded problem: group moments all-reduced, same guess on every rank
             gm = p.epipolar_moments()
             eul, tg, ncand = p.initial_guess(80, 0.25, 5)
             dist.barrier()
             p.peer_disable()
-        q.put((rank, used, packs, r, t, s.num_iterations, tr, (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost), (gm, eul, tg, ncand)))
+        q.put((rank, used, packs, r, t, s.num_iterations, tr,
+               (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost, d_ls, sd_ls.num_iterations, sd_ls.num_line_search_steps,
+                sd_ls.final_cost),
+               (gm, eul, tg, ncand)))
     except Exception as e:      # surface the failure in the parent instead of a silent timeout
         import traceback
         q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None, None, None))
@@ -80,6 +88,9 @@ def test_peer_exchange_processes_on_one_gpu(world):
         r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
         tr1, _, _ = p.solve(api.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
         d1, sd1 = p.solve_depths(c.rot_true, c.tran_true)
+        p.set_depths(np.ones((N, 2)))
+        d1_ls, sd1_ls = p.solve_depths(c.rot_init, c.tran_init)
+    assert sd1_ls.num_line_search_steps >= 1                 # the case really contracts a step
     total_moments = sum(m for m in _shard_moments(c, world))
     for rank, used, packs, r, t, iters, tr, depth, guess in res:
         for pk in packs:
@@ -88,11 +99,14 @@ def test_peer_exchange_processes_on_one_gpu(world):
         assert np.array_equal(r, res[0][3]) and np.array_equal(t, res[0][4])   # lock-step LM
         assert iters == s1.num_iterations and np.abs(r - r1).max() <= 1e-11 and np.abs(t - t1).max() <= 1e-11
         assert np.abs(tr - tr1).max() <= 1e-11
-        lo, hi, d, d_iters, d_term, d_cost = depth
+        lo, hi, d, d_iters, d_term, d_cost, d_ls, ls_iters, ls_steps, ls_cost = depth
         assert (d_iters, d_term) == (sd1.num_iterations, sd1.termination)
         assert d_cost == res[0][7][5]                                            # the same reduced numbers on every rank
         assert abs(d_cost - sd1.final_cost) <= 1e-12 * sd1.final_cost
         assert np.abs(d - d1[lo:hi]).max() <= 1e-9
+        assert (ls_iters, ls_steps) == (sd1_ls.num_iterations, sd1_ls.num_line_search_steps)
+        assert ls_cost == res[0][7][9] and abs(ls_cost - sd1_ls.final_cost) <= 1e-10 * sd1_ls.final_cost
+        assert np.abs(d_ls - d1_ls[lo:hi]).max() <= 1e-7 * max(1.0, np.abs(d1_ls).max())
         gm, eul, tg, ncand = guess
         assert np.array_equal(gm, res[0][8][0]) and np.array_equal(eul, res[0][8][1]) and np.array_equal(tg, res[0][8][2])
         assert np.abs(gm - total_moments).max() <= 1e-12 * np.abs(total_moments).max()

@@ -171,6 +171,20 @@ def test_rotate_keypoints_and_crop_bit_exact_every_pitch(oracle, H, W):
             assert decided == (H // 4) * W                    # every pixel is an exact tie: all decided by the host
 
 
+def test_coordinate_maps_golden_fixtures():
+    """The HIP maps against the COMMITTED fixtures (tests/golden/maps.npz): every result bit-identical."""
+    from helpers import GOLDEN
+    m = np.load(GOLDEN / "maps.npz", allow_pickle=False)
+    H, W, S = (int(v) for v in m["geometry"])
+    for pitch in (45.0, -45.0, -90.0, 0.0):
+        tag = f"p{int(pitch)}".replace("-", "m")
+        assert np.array_equal(api.rotate_keypoints(m["kp"], pitch, W, H)[:, :2], m[f"rotate_{tag}"]), pitch
+        assert np.array_equal(api.crop_rotated_image(m["im"], pitch), m[f"crop_{tag}"]), pitch
+    got = api.cube2equi_keypoints(m["cube_kp"], S, W, H)[:, :2]
+    assert np.array_equal(got.view(np.uint32), m["cube2equi"].view(np.uint32))
+    assert np.array_equal(api.equi2cube(m["im"], S), m["equi2cube"])
+
+
 def test_matcher_coordinate_maps(oracle):
     """rotate_keypoint on real-valued key-points, cube2equi_pixel (equi2cube_surf.cpp:19-76; float32 results, compared
     bit for bit), device-resident variants, batched crop."""

@@ -315,3 +315,29 @@ def test_lm_trajectory_vs_independent_numpy_restatement(oracle, mode, n, seed):
     assert (term, s_o.num_iterations, s_o.num_successful_steps) == (info["termination"], info["iterations"], info["successful"])
     assert np.abs(r_o - r_n).max() <= 1e-9 and np.abs(t_o - t_n).max() <= 1e-9
     assert abs(s_o.final_cost - info["cost"]) <= 1e-10 * info["cost"] and abs(s_o.initial_cost - info["initial_cost"]) <= 1e-10 * info["initial_cost"]
+
+
+def test_depth_stage_and_maps_golden(oracle):
+    """The committed fixtures of the d-only stage (with and without Ceres' line search) and of the coordinate maps:
+    the oracle must reproduce them exactly (same build flags, same libm)."""
+    z = np.load(GOLDEN / "depth_stage.npz", allow_pickle=False)
+    for name in ("ls_d1", "ls_d005", "ls_reg", "plain_d2"):
+        d0, lam, c_ = z[f"{name}_cfg"]
+        n = len(z[f"{name}_x1"])
+        for tag, ls in (("ceres", 20), ("nols", 0)):
+            d, s, rc = oracle.depth_solve(z[f"{name}_x1"], z[f"{name}_x2"], z[f"{name}_rot"], z[f"{name}_tran"],
+                                          np.full((n, 2), d0), lam=lam, c=c_,
+                                          options=oracle.default_options(max_num_line_search_step_size_iterations=ls))
+            meta = z[f"{name}_{tag}_meta"]
+            assert rc == 0 and np.array_equal(d, z[f"{name}_{tag}_d"]), (name, tag)
+            assert (s.termination, s.num_iterations, s.num_successful_steps, s.num_line_search_steps) == tuple(int(v) for v in meta[:4])
+    assert z["ls_d1_ceres_meta"][3] >= 1 and z["ls_d1_nols_meta"][1] > z["ls_d1_ceres_meta"][1]     # the search matters here
+    assert np.array_equal(z["plain_d2_ceres_d"], z["plain_d2_nols_d"])                                # ... and not here
+    m = np.load(GOLDEN / "maps.npz", allow_pickle=False)
+    H, W, S = (int(v) for v in m["geometry"])
+    for pitch in (45.0, -45.0, -90.0, 0.0):
+        tag = f"p{int(pitch)}".replace("-", "m")
+        assert np.array_equal(oracle.rotate_keypoints(m["kp"], pitch, W, H)[:, :2], m[f"rotate_{tag}"])
+        assert np.array_equal(oracle.crop_rotated_image(m["im"], pitch), m[f"crop_{tag}"])
+    assert np.array_equal(oracle.cube2equi_keypoints(m["cube_kp"], S, W, H)[:, :2], m["cube2equi"])
+    assert np.array_equal(oracle.equi2cube(m["im"], S)[0], m["equi2cube"])
