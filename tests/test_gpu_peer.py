@@ -15,6 +15,7 @@ from spherical_bundle_adjuster_amd import api, synthetic
 pytestmark = pytest.mark.gpu
 
 N = 60001
+LS_N = 500
 
 
 def _worker(rank, world, port, q):
@@ -38,18 +39,24 @@ def _worker(rank, world, port, q):
             tr, _, _ = p.solve(A.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
             # d-only stage on the sharded problem: six global reductions exchanged per pass, identical step logic
             d, sd = p.solve_depths(c.rot_true, c.tran_true)
-            # ... and from a start whose full step fails Armijo: the line search's contraction passes are sharded too
-            p.set_depths(np.ones((hi - lo, 2)))
-            d_ls, sd_ls = p.solve_depths(c.rot_init, c.tran_init)
-            p.set_depths(d)
             # 8-point initial guess on the sharded problem: group moments all-reduced, same guess on every rank
             gm = p.epipolar_moments()
             eul, tg, ncand = p.initial_guess(80, 0.25, 5)
             dist.barrier()
             p.peer_disable()
+        # ... and a small problem whose first full step fails Armijo (500 matches, start d = 1: one contraction to
+        # a = 0.49): the line search's extra passes are sharded and all-reduced like every other pass
+        c2 = syn.full_rt(LS_N, seed=6)
+        lo2, hi2 = syn.shard_range(LS_N, rank, world)
+        with A.Problem(0) as p2:
+            p2.upload(c2.x1[lo2:hi2], c2.x2[lo2:hi2], np.ones((hi2 - lo2, 2)))
+            distributed.attach(p2, transport="peer")
+            d_ls, sd_ls = p2.solve_depths(c2.rot_init, c2.tran_init)
+            dist.barrier()
+            p2.peer_disable()
         q.put((rank, used, packs, r, t, s.num_iterations, tr,
                (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost, d_ls, sd_ls.num_iterations, sd_ls.num_line_search_steps,
-                sd_ls.final_cost),
+                sd_ls.final_cost, lo2, hi2),
                (gm, eul, tg, ncand)))
     except Exception as e:      # surface the failure in the parent instead of a silent timeout
         import traceback
@@ -88,8 +95,10 @@ def test_peer_exchange_processes_on_one_gpu(world):
         r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
         tr1, _, _ = p.solve(api.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
         d1, sd1 = p.solve_depths(c.rot_true, c.tran_true)
-        p.set_depths(np.ones((N, 2)))
-        d1_ls, sd1_ls = p.solve_depths(c.rot_init, c.tran_init)
+    c2 = synthetic.full_rt(LS_N, seed=6)
+    with api.Problem(0) as p:
+        p.upload(c2.x1, c2.x2, np.ones((LS_N, 2)))
+        d1_ls, sd1_ls = p.solve_depths(c2.rot_init, c2.tran_init)
     assert sd1_ls.num_line_search_steps >= 1                 # the case really contracts a step
     total_moments = sum(m for m in _shard_moments(c, world))
     for rank, used, packs, r, t, iters, tr, depth, guess in res:
@@ -99,14 +108,14 @@ def test_peer_exchange_processes_on_one_gpu(world):
         assert np.array_equal(r, res[0][3]) and np.array_equal(t, res[0][4])   # lock-step LM
         assert iters == s1.num_iterations and np.abs(r - r1).max() <= 1e-11 and np.abs(t - t1).max() <= 1e-11
         assert np.abs(tr - tr1).max() <= 1e-11
-        lo, hi, d, d_iters, d_term, d_cost, d_ls, ls_iters, ls_steps, ls_cost = depth
+        lo, hi, d, d_iters, d_term, d_cost, d_ls, ls_iters, ls_steps, ls_cost, lo2, hi2 = depth
         assert (d_iters, d_term) == (sd1.num_iterations, sd1.termination)
         assert d_cost == res[0][7][5]                                            # the same reduced numbers on every rank
         assert abs(d_cost - sd1.final_cost) <= 1e-12 * sd1.final_cost
         assert np.abs(d - d1[lo:hi]).max() <= 1e-9
         assert (ls_iters, ls_steps) == (sd1_ls.num_iterations, sd1_ls.num_line_search_steps)
         assert ls_cost == res[0][7][9] and abs(ls_cost - sd1_ls.final_cost) <= 1e-10 * sd1_ls.final_cost
-        assert np.abs(d_ls - d1_ls[lo:hi]).max() <= 1e-7 * max(1.0, np.abs(d1_ls).max())
+        assert np.abs(d_ls - d1_ls[lo2:hi2]).max() <= 1e-7 * max(1.0, np.abs(d1_ls).max())
         gm, eul, tg, ncand = guess
         assert np.array_equal(gm, res[0][8][0]) and np.array_equal(eul, res[0][8][1]) and np.array_equal(tg, res[0][8][2])
         assert np.abs(gm - total_moments).max() <= 1e-12 * np.abs(total_moments).max()
@@ -136,3 +145,25 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     assert b["lm"]["termination"].startswith("CONVERGENCE") and "cpu_baseline" not in b
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in b["roofline"]
+
+
+def test_bench_c5_two_rank_rehearsal(tmp_path):
+    """bench.py --workload c5 for N = 2 in the one-GPU rehearsal mode: pairs are independent (no collective), every rank
+    holds its own pairs, rank 0 prints ONE line with the totals."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SBA_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "5", "--warmup",
+           "1", "--workload", "c5", "--pairs", "256", "--pair-matches", "2000", "--frames", "2", "--precondition-ms", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 5 and b["scaling"] == "weak" and b["config"]["pairs_per_gpu"] == 256
+    assert abs(b["value"] - 2 * 256 * 2000 * 5 / (b["ms_per_step"] * 1e-3 * 5)) <= 1e-6 * b["value"]
+    assert b["lm"]["all_converged"] and "cpu_baseline" not in b and b["equi2cube"]["frames"] == 2
