@@ -50,6 +50,7 @@ struct sba_batch {
   bool publish = true;                        // SBA_PUBLISH=0: D2H copy + stream synchronise instead
   sba::BatchLmIo* lm_io_host = nullptr;       // pinned + mapped: per-pair start point in, result + summary out (batch_lm_kernel)
   sba::BatchLmIo* lm_io_host_dev = nullptr;   // device-visible address of lm_io_host
+  unsigned int* lm_ticket = nullptr;          // device: blocks of batch_lm_kernel that have delivered their record
 };
 
 namespace {
@@ -66,7 +67,8 @@ int free_batch_data(sba_batch* b) {
   if (b->packs_dev) SBA_TRY_HIP(hipFree(b->packs_dev));
   if (b->packs_host) SBA_TRY_HIP(hipHostFree(b->packs_host));
   if (b->lm_io_host) SBA_TRY_HIP(hipHostFree(b->lm_io_host));
-  b->lm_io_host = nullptr; b->lm_io_host_dev = nullptr;
+  if (b->lm_ticket) SBA_TRY_HIP(hipFree(b->lm_ticket));
+  b->lm_io_host = nullptr; b->lm_io_host_dev = nullptr; b->lm_ticket = nullptr;
   b->desc_dev = nullptr; b->params_dev = nullptr; b->state_host = nullptr; b->state_host_dev = nullptr;
   b->frames_dev = nullptr; b->partials = nullptr;
   b->packs_dev = nullptr; b->packs_host = nullptr; b->packs_host_dev = nullptr;
@@ -307,6 +309,8 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
                             hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(b->lm_io_host, 0, sizeof(sba::BatchLmIo) * num_pairs);
   SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->lm_io_host_dev), b->lm_io_host, 0));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->lm_ticket), 64));
+  SBA_TRY_HIP(hipMemset(b->lm_ticket, 0, 64));
   b->seq = 0;
 
   // stage the AoS arrays whole, then re-lay each pair out at its plane offset
@@ -451,8 +455,20 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
     sba::Planes pl;
     for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
     pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
-    SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B, b->stream));
-    SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    // completion word: the slot after the packs in the mapped host buffer (the same one the batched step publishes to)
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B);
+    unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(b->packs_host_dev + 24 * B);
+    if (b->publish) {
+      const unsigned long long seq = ++b->seq;
+      SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B,
+                                       b->lm_ticket, flag_dev, seq, b->stream));
+      const int wrc = sba::wait_for_sequence(flag, seq, b->stream, "batched per-pair solve");
+      if (wrc) return wrc;
+    } else {
+      SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B,
+                                       b->lm_ticket, nullptr, 0, b->stream));
+      SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    }
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     int failures = 0;
     for (int g = 0; g < B; ++g) {

@@ -190,7 +190,10 @@ __global__ __launch_bounds__(1024) void batch_convert_finalize_kernel(const doub
 // the iteration counter or terminates).
 template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
 __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairDesc* __restrict__ desc,
-                                                         BatchLmIo* __restrict__ io, sba_lm_options opt) {
+                                                         BatchLmIo* __restrict__ io, sba_lm_options opt,
+                                                         unsigned int* __restrict__ ticket,
+                                                         unsigned long long* __restrict__ seq_host,
+                                                         unsigned long long seq) {
   constexpr int NACC = AccMap<MODE, KIND>::N;
   constexpr int PPT = Lanes<ST>::PPT;
   __shared__ double wave_out[(kBlock / 64) * 24];
@@ -212,13 +215,24 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     new (solver) LmSolver();
     solver->start(MODE, in.rot, in.tran, opt);
   }
+#ifdef SBA_LM_PROFILE
+  long long tk_prep = 0, tk_sweep = 0, tk_conv = 0, tk_feed = 0, tk0 = 0;
+#define SBA_TICK(acc) do { const long long now_ = wall_clock64(); acc += now_ - tk0; tk0 = now_; } while (0)
+#else
+#define SBA_TICK(acc) do { } while (0)
+#endif
   for (;;) {
     if (tid == 0) {
+#ifdef SBA_LM_PROFILE
+      tk0 = wall_clock64();
+#endif
       done_s = solver->done() ? 1 : 0;
       if (!done_s) {
-        fill_sweep_params(n, DEPTH, solver->query_rot(), solver->query_tran(), depth_s[0], depth_s[1], opt.huber_delta, &prm_s);
+        fill_sweep_params(n, DEPTH, solver->query_rot(), solver->query_tran(), depth_s[0], depth_s[1], opt.huber_delta, &prm_s,
+                          KIND == KIND_EXPLICIT);
         if (KIND == KIND_FACTORED && MODE != MODE_TRAN) factored_frame(solver->query_rot(), frame_s, frame_s + 9);
       }
+      SBA_TICK(tk_prep);
     }
     __syncthreads();
     if (done_s) break;
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     }
     __syncthreads();
     if (tid == 0) {
+      SBA_TICK(tk_sweep);
       double pack[24];
       if (KIND == KIND_FACTORED && MODE != MODE_TRAN)
         moments_to_normal_pack(true, MODE == MODE_RT, frame_s, frame_s + 9, raw_s, pack);
@@ -264,7 +279,9 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
         for (int k = 0; k < 24; ++k) pack[k] = raw_s[k];
       sba_normal_eq ne;
       expand_pack(MODE, pack, &ne);
+      SBA_TICK(tk_conv);
       solver->feed(ne);
+      SBA_TICK(tk_feed);
     }
     // thread 0 re-enters the loop head alone; everybody else waits at its barrier
   }
@@ -273,9 +290,26 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     for (int a = 0; a < 3; ++a) { res.rot[a] = solver->rot()[a]; res.tran[a] = solver->tran()[a]; }
     res.d1 = depth_s[0]; res.d2 = depth_s[1];
     res.summary = solver->summary();
+#ifdef SBA_LM_PROFILE
+    // ticks of the 100 MHz wall clock spent by thread 0 in: preparation / waiting for the sweep / conversion / LM feed
+    res.summary.initial_cost = static_cast<double>(tk_prep); res.summary.final_cost = static_cast<double>(tk_sweep);
+    res.summary.final_gradient_max_norm = static_cast<double>(tk_conv); res.summary.final_radius = static_cast<double>(tk_feed);
+#endif
     res.status = solver->status();
     res.pad_ = 0;
     io[pair] = res;
+    // Completion: this block's record is in host memory (system-scope release + vmcnt(0)) before it takes a ticket; the
+    // block that takes the last ticket re-arms the counter and stores the sequence word the host polls -- no stream
+    // synchronise (that alone cost ~50 us of a 0.6 ms solve).
+    if (seq_host) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(seq_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -306,7 +340,8 @@ BatchFn bpick(int mode, int depth, int store, int kind, bool loss) {
   return nullptr;
 }
 
-typedef void (*BatchLmFn)(Planes, const PairDesc*, BatchLmIo*, sba_lm_options);
+typedef void (*BatchLmFn)(Planes, const PairDesc*, BatchLmIo*, sba_lm_options, unsigned int*, unsigned long long*,
+                          unsigned long long);
 template <int MODE, int DEPTH, typename ST, int KIND>
 BatchLmFn lpick_loss(bool loss) {
   return loss ? batch_lm_kernel<MODE, DEPTH, ST, KIND, true> : batch_lm_kernel<MODE, DEPTH, ST, KIND, false>;
@@ -335,11 +370,13 @@ BatchLmFn lpick(int mode, int depth, int store, int kind, bool loss) {
 }  // namespace
 
 hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
-                           BatchLmIo* io, const sba_lm_options& opt, int num_pairs, hipStream_t stream) {
+                           BatchLmIo* io, const sba_lm_options& opt, int num_pairs, unsigned int* ticket,
+                           unsigned long long* seq_host_dev, unsigned long long seq, hipStream_t stream) {
   if (num_pairs <= 0) return hipSuccess;
   BatchLmFn fn = lpick(mode, depth, store, kind, opt.huber_delta > 0.0);
   if (!fn) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs)), dim3(kBlock), 0, stream, pl, desc, io, opt);
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs)), dim3(kBlock), 0, stream, pl, desc, io, opt, ticket,
+                     seq_host_dev, seq);
   return hipGetLastError();
 }
 

@@ -27,13 +27,15 @@ struct SweepParams {
 static_assert(sizeof(SweepParams) == 43 * 8, "SweepParams layout");
 
 // Per-sweep state from (rot, tran, depths, delta).  depth_mode: 0 = uniform (d1 folded into Rn / Gn), 1 = per match.
+// with_derivatives = false (the factored kernel never reads Gn): Gn is zeroed, d R / d w is not formed.
 SBA_HD inline void fill_sweep_params(unsigned long long n, int depth_mode, const double rot[3], const double tran[3],
-                                     double d1, double d2, double huber_delta, SweepParams* prm) {
+                                     double d1, double d2, double huber_delta, SweepParams* prm,
+                                     bool with_derivatives = true) {
   double R[9], G[27];
-  rotation_and_derivatives(rot, R, G);
+  rotation_and_derivatives(rot, R, with_derivatives ? G : nullptr);
   const double scale = depth_mode == 0 ? -d1 : -1.0;
   for (int i = 0; i < 9; ++i) prm->Rn[i] = scale * R[i];
-  for (int i = 0; i < 27; ++i) prm->Gn[i] = scale * G[i];
+  for (int i = 0; i < 27; ++i) prm->Gn[i] = with_derivatives ? scale * G[i] : 0.0;
   for (int i = 0; i < 3; ++i) prm->t[i] = tran[i];
   prm->d2 = d2;
   prm->delta = huber_delta > 0.0 ? huber_delta : 0.0;
@@ -127,8 +129,11 @@ struct BatchLmIo {
   int status;
   int pad_;
 };
+// ticket: one zeroed device word; seq_host_dev (may be null): device-visible address of a host word that receives `seq`
+// once every pair's record has been written.
 hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
-                           BatchLmIo* io, const sba_lm_options& opt, int num_pairs, hipStream_t stream);
+                           BatchLmIo* io, const sba_lm_options& opt, int num_pairs, unsigned int* ticket,
+                           unsigned long long* seq_host_dev, unsigned long long seq, hipStream_t stream);
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,

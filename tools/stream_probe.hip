@@ -89,6 +89,37 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(PlanePtrs pl, size_t nvec
   }
 }
 
+// Mixed read / write stream (the d-only stage's pattern): NR planes read once (nt loads), NW planes written once (nt
+// stores), 16 B per lane, grid-stride, next step's loads in flight while the current step is stored.
+struct MixedPtrs { const double2* r[12]; double2* w[4]; };
+template <int NR, int NW>
+__global__ __launch_bounds__(kBlock) void mixed_kernel(MixedPtrs pl, size_t nvec) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
+  size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  double2 cur[NR], nxt[NR];
+  if (p < nvec)
+#pragma unroll
+    for (int k = 0; k < NR; ++k) cur[k] = ld<true>(pl.r[k] + p);
+  while (p < nvec) {
+    const size_t pn = p + stride;
+    if (pn < nvec)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) nxt[k] = ld<true>(pl.r[k] + pn);
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { sx += cur[k].x; sy += cur[k].y; }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const double2 q = make_double2(sx + k, sy - k);
+      __builtin_nontemporal_store(*reinterpret_cast<const f4*>(&q), reinterpret_cast<f4*>(pl.w[k] + p));
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) cur[k] = nxt[k];
+    p = pn;
+  }
+}
+
 typedef void (*Kern)(PlanePtrs, size_t, double*, unsigned long long*);
 
 struct Variant { const char* name; Kern k; };
@@ -97,6 +128,7 @@ int main(int argc, char** argv) {
   const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 10000000ull;
   const int launches = argc > 2 ? std::atoi(argv[2]) : 50;
   const bool quick = argc > 3 && std::string(argv[3]) == "quick";   // bench.py: only the sweep kernel's pattern, one JSON line
+  const bool mixed = argc > 3 && std::string(argv[3]) == "mixed";   // the d-only stage's read + write pattern
   const size_t nvec = n / 2;
   const size_t stagger = 4352;
   hipDeviceProp_t prop;
@@ -106,6 +138,40 @@ int main(int argc, char** argv) {
     std::printf("# %s, %d CUs, n = %zu matches, %d planes x %.1f MB = %.1f MB per launch\n", prop.name, cus, n, kPlanes,
                 n * 8 / 1e6, n * 8.0 * kPlanes / 1e6);
 
+  if (mixed) {
+    const size_t nv = n / 2;
+    MixedPtrs mp;
+    void* mb[16];
+    for (int k = 0; k < 16; ++k) {
+      CHECK(hipMalloc(&mb[k], (nv + 1) * 16 + 16 * stagger));
+      CHECK(hipMemset(mb[k], 0x3c, (nv + 1) * 16 + 16 * stagger));
+      if (k < 12) mp.r[k] = reinterpret_cast<const double2*>(static_cast<char*>(mb[k]) + k * stagger);
+      else mp.w[k - 12] = reinterpret_cast<double2*>(static_cast<char*>(mb[k]) + k * stagger);
+    }
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    struct { const char* name; void (*k)(MixedPtrs, size_t); int nr, nw; } mv[] = {
+        {"10 read + 2 written (pass with the diagonal reused)", mixed_kernel<10, 2>, 10, 2},
+        {" 8 read + 4 written (pass that stores a new diagonal)", mixed_kernel<8, 4>, 8, 4},
+        {"12 read + 0 written", mixed_kernel<12, 0>, 12, 0},
+        {" 8 read + 0 written (the sweep's planes)", mixed_kernel<8, 0>, 8, 0}};
+    for (auto& v : mv)
+      for (int bpc : {1, 2, 4}) {
+        const int grid = cus * bpc;
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(v.k, dim3(grid), dim3(kBlock), 0, nullptr, mp, nv);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(v.k, dim3(grid), dim3(kBlock), 0, nullptr, mp, nv);
+        CHECK(hipEventRecord(b, nullptr));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        const double us = ms * 1e3 / launches, bytes = static_cast<double>(nv) * 16 * (v.nr + v.nw);
+        std::printf("mixed %-55s %d blocks/CU  %7.1f us  %6.0f GB/s (read + written)\n", v.name, bpc, us, bytes / us * 1e-3);
+      }
+    for (int k = 0; k < 16; ++k) CHECK(hipFree(mb[k]));
+    return 0;
+  }
   PlanePtrs pl;
   void* base[kPlanes];
   for (int k = 0; k < kPlanes; ++k) {
