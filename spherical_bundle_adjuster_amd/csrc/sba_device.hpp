@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "../../include/sba_hip.h"
+#include "sba_depth_solver.hpp"
 #include "sba_rotation.hpp"
 
 namespace sba {
@@ -173,19 +174,7 @@ struct DepthParams {
   int pad_;
   unsigned long long n;
 };
-// Results of one pass (DEPTH_OUT_* slots of out / host_out): seven sums and two maxima.
-enum {
-  DEPTH_OUT_COST = 0,       // cost at d
-  DEPTH_OUT_MODEL = 1,      // model cost change of the trust-region step delta
-  DEPTH_OUT_CAND_COST = 2,  // cost at the candidate P(d + alpha delta)
-  DEPTH_OUT_STEP2 = 3,      // |candidate - d|^2
-  DEPTH_OUT_X2 = 4,         // |d|^2
-  DEPTH_OUT_GDELTA = 5,     // gradient(d) . delta                         (line search: initial slope)
-  DEPTH_OUT_CAND_GDELTA = 6,// gradient(candidate) . delta                 (line search: slope at the trial point)
-  DEPTH_OUT_GMAX = 7,       // max: projected gradient max-norm at d
-  DEPTH_OUT_DMAX = 8,       // max: |delta|_inf
-  DEPTH_OUT_SUMS = 7, DEPTH_OUT_COUNT = 9, DEPTH_ROW = 16
-};
+// Results of one pass: the DEPTH_OUT_* slots of out / host_out (sba_depth_solver.hpp): seven sums and two maxima.
 // gather_slot >= 0 (sharded problem): `out` is a 24-double pack for a SUM all-reduce, the sums in [0..6], this rank's
 // two maxima in [8 + gather_slot] and [16 + gather_slot] (gather_slot < 8), zeros elsewhere; nothing is published to
 // the host.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.  partials: [grid][16].

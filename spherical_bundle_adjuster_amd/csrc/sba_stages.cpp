@@ -6,8 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "sba_depth_solver.hpp"
 #include "sba_epipolar.hpp"
-#include "sba_line_search.hpp"
 #include "sba_lm.hpp"
 #include "sba_problem.hpp"
 #include "sba_rotation.hpp"
@@ -75,16 +75,13 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
 
   double* cur1 = p->dplane[0];
   double* cur2 = p->dplane[1];
-  double radius = o.initial_trust_region_radius, nu = 2.0;
-  bool reuse = false, first = true;
-  int invalid = 0, rc_final = SBA_OK;
+  int rc_final = SBA_OK;
   double out[sba::DEPTH_OUT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   // One device pass at the current depths: the step delta of the damped system, the candidate P(d + alpha delta)
-  // into (c1, c2), and the nine reductions.  keep_diagonal: use the stored LM diagonal (after a rejected step, and
-  // for every line-search pass, whose delta must be the trust-region step's).
-  auto pass = [&](double alpha, bool keep_diagonal) -> int {
-    prm.radius = radius; prm.inv_radius = 1.0 / radius; prm.alpha = alpha;
-    prm.first_iteration = first ? 1 : 0; prm.reuse_diagonal = keep_diagonal ? 1 : 0;
+  // into (c1, c2), and the nine reductions -- all-reduced when the problem is sharded.
+  auto pass = [&](const sba::DepthPassRequest& rq) -> int {
+    prm.radius = rq.radius; prm.inv_radius = 1.0 / rq.radius; prm.alpha = rq.alpha;
+    prm.first_iteration = rq.first ? 1 : 0; prm.reuse_diagonal = rq.keep_diagonal ? 1 : 0;
     if (collective) {
       SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
                                          p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
@@ -99,8 +96,6 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
         out[sba::DEPTH_OUT_GMAX] = std::max(out[sba::DEPTH_OUT_GMAX], raw[8 + r]);
         out[sba::DEPTH_OUT_DMAX] = std::max(out[sba::DEPTH_OUT_DMAX], raw[16 + r]);
       }
-      sum->num_evaluations++;
-      first = false;
       return SBA_OK;
     }
     if (p->publish) {
@@ -118,71 +113,22 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
       SBA_TRY_HIP(hipStreamSynchronize(p->stream));
     }
     std::memcpy(out, p->pack_host, sizeof(out));
-    sum->num_evaluations++;
-    first = false;
     return SBA_OK;
   };
-  auto finish = [&](int term, double cost, double gmax) {
-    sum->termination = term; sum->final_cost = cost; sum->final_gradient_max_norm = gmax; sum->final_radius = radius;
-    sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-  };
 
-  for (int it = 0;;) {     // `it` = trust-region iterations completed
-    int rc = pass(1.0, reuse);
+  // The step logic (trust region + Ceres' projected line search) is a host state machine, sba_depth_solver.hpp: it
+  // names the next pass, is fed the pass's reductions, and says when the candidate planes become the current depths.
+  sba::DepthStageSolver solver;
+  solver.start(o);
+  while (!solver.done()) {
+    const int rc = pass(solver.request());
     if (rc) return rc;
-    const double cost = out[sba::DEPTH_OUT_COST], model = out[sba::DEPTH_OUT_MODEL], gmax = out[sba::DEPTH_OUT_GMAX];
-    if (it == 0) {
-      sum->initial_cost = cost;
-      if (!std::isfinite(cost)) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
-    }
-    // Ceres' end-of-iteration checks, in its order (the gradient at the current point arrives with this pass)
-    if (it >= o.max_num_iterations) { finish(SBA_TERM_NO_CONVERGENCE, cost, gmax); break; }
-    if (gmax <= o.gradient_tolerance) { finish(SBA_TERM_CONVERGENCE_GRADIENT, cost, gmax); break; }
-    if (radius < o.min_trust_region_radius) { finish(SBA_TERM_MIN_RADIUS, cost, gmax); break; }
-    sum->num_iterations = ++it;
-    if (!(model > 0.0)) {
-      if (++invalid >= 5) { finish(SBA_TERM_FAILURE, cost, gmax); rc_final = SBA_ERR_NUMERIC; break; }
-      radius /= nu; nu *= 2.0; reuse = true;
-      continue;
-    }
-    invalid = 0;
-    const double x2n = out[sba::DEPTH_OUT_X2];
-    if (o.max_num_line_search_step_size_iterations > 0) {
-      // Ceres' DoLineSearch (bounds-constrained problem): the pass above already holds the first trial (alpha = 1);
-      // a contraction re-runs it at the step size the search asks for, with the same delta.
-      sba::ls::ArmijoSearch search;
-      search.start(o, cost, out[sba::DEPTH_OUT_GDELTA], out[sba::DEPTH_OUT_DMAX]);
-      search.feed(out[sba::DEPTH_OUT_CAND_COST], out[sba::DEPTH_OUT_CAND_GDELTA]);
-      double planes_alpha = 1.0;     // the step size the candidate planes / out[] currently belong to
-      while (!search.done()) {
-        planes_alpha = search.query();
-        rc = pass(planes_alpha, true);
-        if (rc) return rc;
-        search.feed(out[sba::DEPTH_OUT_CAND_COST], out[sba::DEPTH_OUT_CAND_GDELTA]);
-      }
-      sum->num_line_search_steps += search.num_iterations();
-      if (search.step_size() != planes_alpha) {     // failed search: Ceres keeps the full step
-        rc = pass(search.step_size(), true);
-        if (rc) return rc;
-      }
-    }
-    const double cand_cost = out[sba::DEPTH_OUT_CAND_COST];
-    if (std::sqrt(out[sba::DEPTH_OUT_STEP2]) <= o.parameter_tolerance * (std::sqrt(x2n) + o.parameter_tolerance)) {
-      finish(SBA_TERM_CONVERGENCE_PARAMETER, cost, gmax); break;
-    }
-    const double change = cost - cand_cost;
-    if (std::fabs(change) <= o.function_tolerance * cost) { finish(SBA_TERM_CONVERGENCE_FUNCTION, cost, gmax); break; }
-    const double quality = change / model;
-    if (quality > o.min_relative_decrease) {
-      std::swap(cur1, c1); std::swap(cur2, c2);     // the candidate planes become the current depths
-      sum->num_successful_steps++;
-      const double q = 2.0 * quality - 1.0;
-      radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - q * q * q));
-      nu = 2.0; reuse = false;
-    } else {
-      radius /= nu; nu *= 2.0; reuse = true;
-    }
+    solver.feed(out);
+    if (solver.take_candidate()) { std::swap(cur1, c1); std::swap(cur2, c2); }
   }
+  *sum = solver.summary();
+  sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  rc_final = solver.status();
   // the problem's depth planes must end up holding the result
   if (cur1 != p->dplane[0]) {
     SBA_TRY_HIP(hipMemcpyAsync(p->dplane[0], cur1, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
