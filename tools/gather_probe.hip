@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -117,6 +118,22 @@ __global__ __launch_bounds__(256) void gather_pix1x(const int* __restrict__ tabl
     }
   for (; f < f1; ++f) store(out + static_cast<size_t>(f) * out_stride, load(src + static_cast<size_t>(f) * src_stride));
 }
+// variant 9: entries sorted by SOURCE index (lanes of a wave read neighbouring source pixels: few lines per load
+// instruction even on the polar faces), scattered 3-byte stores to out[dst[k]]
+__global__ __launch_bounds__(256) void gather_sorted(const int2* __restrict__ pairs, size_t out_pixels, const uint8_t* __restrict__ src,
+                                                     size_t src_stride, uint8_t* __restrict__ out, size_t out_stride, int batch, int fpb) {
+  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= out_pixels) return;
+  const int2 e = pairs[g];
+  const size_t p = static_cast<size_t>(e.x) * 3, o = static_cast<size_t>(e.y) * 3;
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    uint8_t* d = out + static_cast<size_t>(f) * out_stride + o;
+    const uint8_t b0 = sa[p], b1 = sa[p + 1], b2 = sa[p + 2];
+    d[0] = b0; d[1] = b1; d[2] = b2;
+  }
+}
 // variant 5: a wave owns 256 consecutive output pixels; round k gathers pixels 64 k + lane (narrow span per instruction),
 // the 768 bytes are transposed through LDS and stored as one dwordx3 per lane
 __global__ __launch_bounds__(256) void gather_lds(const int* __restrict__ table, size_t out_pixels, const uint8_t* __restrict__ src,
@@ -157,12 +174,23 @@ int main(int argc, char** argv) {
   for (int f = 0; f < F; ++f) { h[0] = uint8_t(f); CK(hipMemcpy(src + srcb * f, h.data(), srcb, hipMemcpyHostToDevice)); }
   hipLaunchKernelGGL(table_kernel, dim3((outpx + 255) / 256), dim3(256), 0, 0, S, H, W, table);
   CK(hipDeviceSynchronize());
+  // sorted (source, destination) pairs for variant 9
+  int2* pairs;
+  {
+    std::vector<int> ht(outpx);
+    CK(hipMemcpy(ht.data(), table, outpx * 4, hipMemcpyDeviceToHost));
+    std::vector<int2> hp(outpx);
+    for (size_t i = 0; i < outpx; ++i) hp[i] = make_int2(ht[i], static_cast<int>(i));
+    std::sort(hp.begin(), hp.end(), [](const int2& a, const int2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    CK(hipMalloc(&pairs, outpx * sizeof(int2)));
+    CK(hipMemcpy(pairs, hp.data(), outpx * sizeof(int2), hipMemcpyHostToDevice));
+  }
   const unsigned gx = (outpx / 4 + 255) / 256;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int fpb : {1, 2, 4, 8}) {
     if (fpb > F) break;
     const unsigned gy = (F + fpb - 1) / fpb;
-    for (int v = 4; v < 9; ++v) {
+    for (int v = 7; v < 10; ++v) {
       auto launch = [&](uint8_t* dst) {
         switch (v) {
           case 0: hipLaunchKernelGGL(gather<0>, dim3(gx, gy), dim3(256), 0, 0, table, outpx, src, srcb, H * W, dst, outb, F, fpb); break;
@@ -172,11 +200,12 @@ int main(int argc, char** argv) {
           case 4: hipLaunchKernelGGL(gather_pix1, dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, table, outpx, src, srcb, dst, outb, F, fpb); break;
           case 6: hipLaunchKernelGGL((gather_pix1x<true, false>), dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, table, outpx, src, srcb, dst, outb, F, fpb); break;
           case 7: hipLaunchKernelGGL((gather_pix1x<false, true>), dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, table, outpx, src, srcb, dst, outb, F, fpb); break;
+          case 9: hipLaunchKernelGGL(gather_sorted, dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, pairs, outpx, src, srcb, dst, outb, F, fpb); break;
           case 8: hipLaunchKernelGGL((gather_pix1x<true, true>), dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, table, outpx, src, srcb, dst, outb, F, fpb); break;
           default: hipLaunchKernelGGL(gather_lds, dim3((outpx / 256 + 3) / 4, gy), dim3(256), 0, 0, table, outpx, src, srcb, dst, outb, F, fpb);
         }
       };
-      if (v == 4 && fpb == 1) hipLaunchKernelGGL(gather<0>, dim3(gx, gy), dim3(256), 0, 0, table, outpx, src, srcb, H * W, ref, outb, F, fpb);
+      if (v == 7 && fpb == 1) hipLaunchKernelGGL(gather<0>, dim3(gx, gy), dim3(256), 0, 0, table, outpx, src, srcb, H * W, ref, outb, F, fpb);
       launch(out);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0, 0));
