@@ -368,6 +368,13 @@ int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* r
  * sba_problem_eval_launch_times): launch_ms[i] = device time of launch i.  repeat <= 4096.                        */
 int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
                                  const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms);
+/* The same measurement on the dominant kernel of the step this batch really runs: with one block per pair the whole
+ * step is ONE launch (batch_step_kernel: per-pair state, sweep, fold, conversion; timed here with its publication to
+ * the host switched off), otherwise the batched sweep kernel as above.  sba_batch_step_is_fused: 1 / 0 (negative =
+ * error) -- which of the two it is (SBA_BATCH_FUSED_STEP=0 in the environment keeps the three-kernel chain).        */
+int sba_batch_step_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                                const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms);
+int sba_batch_step_is_fused(const sba_batch* b);
 /* rot / tran are updated in place per pair; summaries (sba_lm_summary[num_pairs]) and status
  * (int[num_pairs], SBA_OK or SBA_ERR_NUMERIC per pair) may be NULL.                                        */
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,

@@ -137,6 +137,9 @@ SIGNATURES = {
                                        _dp, _dp, _dp, _dp]),
     "sba_batch_sweep_launch_times": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int,
                                                C.POINTER(C.c_float)]),
+    "sba_batch_step_launch_times": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int,
+                                              C.POINTER(C.c_float)]),
+    "sba_batch_step_is_fused": (C.c_int, [_vp]),
     "sba_batch_solve": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(LmOptions),
                                   C.POINTER(LmSummary), C.POINTER(C.c_int)]),
     "sba_keypoints_to_sphere": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),

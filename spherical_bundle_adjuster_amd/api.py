@@ -394,17 +394,35 @@ class Batch:
             *[C.cast(C.byref(m), C.POINTER(C.c_double)) for m in ms]))
         return packs, dict(zip(("step_ms", "prepare_ms", "device_ms", "convert_ms"), (m.value for m in ms)))
 
-    def sweep_launch_times(self, mode, rot, tran, d1=None, d2=None, huber_delta=1.0, depth_mode=DEPTH_UNIFORM,
-                           repeat: int = 20) -> np.ndarray:
-        """Device time (ms) of each of `repeat` back-to-back launches of the batched sweep kernel alone."""
+    def _launch_times(self, fn, mode, rot, tran, d1, d2, huber_delta, depth_mode, repeat) -> np.ndarray:
         rot, rp = self._pp(rot, 3)
         tran, tp = self._pp(tran, 3)
         d1a, d1p = self._pp(d1, 1)
         d2a, d2p = self._pp(d2, 1)
         ms = np.zeros(repeat, dtype=np.float32)
-        cabi.check(self._lib, self._lib.sba_batch_sweep_launch_times(
-            self._h, mode, depth_mode, rp, tp, d1p, d2p, huber_delta, repeat, ms.ctypes.data_as(C.POINTER(C.c_float))))
+        cabi.check(self._lib, fn(self._h, mode, depth_mode, rp, tp, d1p, d2p, huber_delta, repeat,
+                                 ms.ctypes.data_as(C.POINTER(C.c_float))))
         return ms.astype(np.float64)
+
+    def sweep_launch_times(self, mode, rot, tran, d1=None, d2=None, huber_delta=1.0, depth_mode=DEPTH_UNIFORM,
+                           repeat: int = 20) -> np.ndarray:
+        """Device time (ms) of each of `repeat` back-to-back launches of the batched sweep kernel alone."""
+        return self._launch_times(self._lib.sba_batch_sweep_launch_times, mode, rot, tran, d1, d2, huber_delta, depth_mode,
+                                  repeat)
+
+    def step_launch_times(self, mode, rot, tran, d1=None, d2=None, huber_delta=1.0, depth_mode=DEPTH_UNIFORM,
+                          repeat: int = 20) -> np.ndarray:
+        """The same for the dominant kernel of the step this batch really runs (`step_is_fused`: the one-launch
+        batch_step_kernel, else the batched sweep kernel)."""
+        return self._launch_times(self._lib.sba_batch_step_launch_times, mode, rot, tran, d1, d2, huber_delta, depth_mode,
+                                  repeat)
+
+    @property
+    def step_is_fused(self) -> bool:
+        rc = self._lib.sba_batch_step_is_fused(self._h)
+        if rc < 0:
+            cabi.check(self._lib, rc)
+        return rc == 1
 
     def solve(self, mode, rot, tran, d1=None, d2=None, depth_mode=DEPTH_UNIFORM, options: cabi.LmOptions | None = None):
         """Per-pair LM in lock-step.  Returns (rot (B,3), tran (B,3), [SolveSummary], status (B,))."""

@@ -93,8 +93,13 @@ int check_batch_args(const sba_batch* b, int mode, int depth_mode, const double*
 // and the finalize kernel folds the rows, maps the factored kernel's moments to the SBA_PACK_* layout (also on the
 // device) and publishes all packs into mapped host memory followed by a sequence word the host polls.  packs_host then
 // holds the final packs.
+bool step_is_fused(const sba_batch* b) {
+  const char* e = std::getenv("SBA_BATCH_FUSED_STEP");      // read per call: tests compare both paths in one process
+  return !(e && e[0] == '0') && b->bpp == 1 && b->publish;
+}
 int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran, const double* d1,
-                 const double* d2, double huber_delta, const unsigned char* active, double* prepare_ms = nullptr) {
+                 const double* d2, double huber_delta, const unsigned char* active, double* prepare_ms = nullptr,
+                 bool allow_fused = true) {
   const int B = b->num_pairs;
   const auto t_prep = std::chrono::steady_clock::now();
   for (int g = 0; g < B; ++g) {
@@ -110,6 +115,16 @@ int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, cons
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
   pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  // One block per pair (config C5): the whole step is ONE launch -- every block prepares its own pair's sweep state,
+  // sweeps, folds, converts its moments and publishes its pack (batch_step_kernel).  SBA_BATCH_FUSED_STEP=0 keeps the
+  // three-kernel chain, which also serves batches that spread a pair over several blocks.
+  if (allow_fused && step_is_fused(b)) {
+    const unsigned long long seq = ++b->seq;
+    SBA_TRY_HIP(sba::launch_batch_step_fused(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
+                                             b->desc_dev, B, b->packs_dev, b->packs_host_dev, b->lm_ticket, seq, b->stream));
+    return sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B), seq, b->stream,
+                                  "batched step");
+  }
   if (!b->publish) {
     SBA_TRY_HIP(sba::launch_batch_step(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
                                        b->params_dev, b->frames_dev, b->desc_dev, B, b->bpp, b->partials, b->packs_dev,
@@ -294,6 +309,7 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->desc_dev), sizeof(sba::PairDesc) * num_pairs));
   SBA_TRY_HIP(hipMemcpy(b->desc_dev, desc.data(), sizeof(sba::PairDesc) * num_pairs, hipMemcpyHostToDevice));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->params_dev), sizeof(sba::SweepParams) * num_pairs));
+  SBA_TRY_HIP(hipMemset(b->params_dev, 0, sizeof(sba::SweepParams) * num_pairs));   // n = 0 until a prepare kernel has run
   SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->state_host), sizeof(sba::BatchState) * num_pairs,
                             hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(b->state_host, 0, sizeof(sba::BatchState) * num_pairs);
@@ -393,14 +409,20 @@ int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* r
   return SBA_OK;
 }
 
-int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
-                                 const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms) {
+namespace {
+// `repeat` launches of one kernel with a HIP event between every two.  step_kernel = false: the bare batch_sweep_kernel;
+// true: the dominant kernel of the step this batch really runs -- batch_step_kernel (publication off: no ticket, no
+// host stores) when the step is fused, batch_sweep_kernel otherwise.
+int kernel_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran, const double* d1,
+                        const double* d2, double huber_delta, int repeat, float* launch_ms, bool step_kernel) {
   int rc = check_batch_args(b, mode, depth_mode, rot, tran);
   if (rc) return rc;
   if (!launch_ms || repeat < 1 || repeat > 4096) return sba::set_error(SBA_ERR_INVALID_ARG, "bad launch_ms/repeat (1..4096)");
   if (b->num_pairs == 0) { for (int i = 0; i < repeat; ++i) launch_ms[i] = 0.f; return SBA_OK; }
   SBA_TRY_HIP(hipSetDevice(b->device));
-  rc = batch_launch(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, nullptr);   // leaves params_dev prepared
+  // the three-kernel chain: its prepare kernel leaves params_dev filled for the bare sweep launches below (the fused
+  // one-launch step keeps every pair's sweep state in LDS and never writes params_dev)
+  rc = batch_launch(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, nullptr, nullptr, false);
   if (rc) return rc;
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
@@ -412,15 +434,35 @@ int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const d
   events.ev.assign(static_cast<size_t>(repeat) + 1, nullptr);
   for (hipEvent_t& e : events.ev) SBA_TRY_HIP(hipEventCreate(&e));
   SBA_TRY_HIP(hipEventRecord(events.ev[0], b->stream));
+  const bool fused = step_kernel && step_is_fused(b);
   for (int i = 0; i < repeat; ++i) {
-    SBA_TRY_HIP(sba::launch_batch_sweep_only(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
-                                             b->desc_dev, b->num_pairs, b->bpp, b->partials, b->stream));
+    if (fused)
+      SBA_TRY_HIP(sba::launch_batch_step_fused(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
+                                               b->desc_dev, b->num_pairs, b->packs_dev, nullptr, b->lm_ticket, 0, b->stream));
+    else
+      SBA_TRY_HIP(sba::launch_batch_sweep_only(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
+                                               b->desc_dev, b->num_pairs, b->bpp, b->partials, b->stream));
     SBA_TRY_HIP(hipEventRecord(events.ev[static_cast<size_t>(i) + 1], b->stream));
   }
   SBA_TRY_HIP(hipEventSynchronize(events.ev[static_cast<size_t>(repeat)]));
   for (int i = 0; i < repeat; ++i)
     SBA_TRY_HIP(hipEventElapsedTime(&launch_ms[i], events.ev[static_cast<size_t>(i)], events.ev[static_cast<size_t>(i) + 1]));
   return SBA_OK;
+}
+}  // namespace
+
+int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                                 const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms) {
+  return kernel_launch_times(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, repeat, launch_ms, false);
+}
+int sba_batch_step_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
+                                const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms) {
+  return kernel_launch_times(b, mode, depth_mode, rot, tran, d1, d2, huber_delta, repeat, launch_ms, true);
+}
+int sba_batch_step_is_fused(const sba_batch* b) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch");
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  return step_is_fused(b) ? 1 : 0;
 }
 
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,

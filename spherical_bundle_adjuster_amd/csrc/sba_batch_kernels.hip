@@ -178,6 +178,126 @@ __global__ __launch_bounds__(1024) void batch_convert_finalize_kernel(const doub
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + items), seq, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// ---- one block = one pair: sweep the pair's matches with `prm` held in registers and fold the block's 24 sums --------
+// (fold order identical to batch_sweep_kernel + batch_convert_finalize_kernel with bpp = 1).  Result in raw_s[24]
+// (LDS), valid after the function returns on every thread (it ends with a barrier).
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__device__ __forceinline__ void block_sweep_fold(const Planes& pl, size_t first, size_t n, const SweepParams& prm,
+                                                 double* __restrict__ wave_out, double* __restrict__ raw_s) {
+  constexpr int NACC = AccMap<MODE, KIND>::N;
+  constexpr int PPT = Lanes<ST>::PPT;
+  const int tid = threadIdx.x;
+  const size_t nfull = n / PPT;
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  size_t p = tid;
+  VecRegs<ST, DEPTH> cur, nxt;
+  if (p < nfull) cur.load(pl, first + p);
+  while (p < nfull) {
+    const size_t pn = p + kBlock;
+    if (pn < nfull) nxt.load(pl, first + pn);
+    consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, &prm, p, n, acc);
+    cur = nxt;
+    p = pn;
+  }
+  if (nfull * PPT != n && tid == kBlock - 1) {
+    cur.load(pl, first + nfull);
+    consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, &prm, nfull, n, acc);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid < 24) raw_s[tid] = 0.0;       // slots no accumulator maps to stay zero
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const double sw = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) wave_out[wave * 24 + AccMap<MODE, KIND>::slot(k)] = sw;
+  }
+  __syncthreads();
+  if (tid < NACC) {
+    const int slot = AccMap<MODE, KIND>::slot(tid);
+    double sum = wave_out[slot];
+#pragma unroll
+    for (int wv = 1; wv < kBlock / 64; ++wv) sum += wave_out[wv * 24 + slot];
+    raw_s[slot] = sum;
+  }
+  __syncthreads();
+}
+
+// ---- one batched evaluation step in ONE launch (bpp == 1) -----------------------------------------------------------
+// What batch_prepare_kernel + batch_sweep_kernel + batch_convert_finalize_kernel do in three launches: thread 0 of block
+// g reads pair g's 80-byte state from mapped host memory and builds the sweep state in LDS, the block sweeps and folds,
+// thread 0 maps the moments to the SBA_PACK_* layout and stores the pack to device and mapped host memory; the block
+// that delivers the last pack stores the sequence word the host polls.
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void batch_step_kernel(Planes pl, const PairDesc* __restrict__ desc,
+                                                           const BatchState* __restrict__ state, double huber_delta,
+                                                           double* __restrict__ packs, double* __restrict__ packs_host,
+                                                           unsigned int* __restrict__ ticket, unsigned long long seq) {
+  __shared__ double wave_out[(kBlock / 64) * 24];
+  __shared__ double raw_s[24];
+  __shared__ SweepParams prm_s;
+  __shared__ double frame_s[18];
+  const int tid = threadIdx.x;
+  const unsigned pair = blockIdx.x;
+#ifdef SBA_STEP_PROFILE
+  long long tk[6] = {0, 0, 0, 0, 0, 0};
+  tk[0] = wall_clock64();
+#endif
+  const size_t n_pair = desc[pair].n, first = desc[pair].first_vec;
+  if (tid == 0) {
+    const BatchState st = state[pair];
+#ifdef SBA_STEP_PROFILE
+    prm_s.n = st.n; __builtin_amdgcn_s_waitcnt(0); tk[1] = wall_clock64();
+#endif
+    fill_sweep_params(st.n, DEPTH, st.rot, st.tran, st.d1, st.d2, huber_delta, &prm_s, KIND == KIND_EXPLICIT);
+    if (KIND == KIND_FACTORED && MODE != MODE_TRAN) factored_frame(st.rot, frame_s, frame_s + 9);
+#ifdef SBA_STEP_PROFILE
+    tk[2] = wall_clock64();
+#endif
+  }
+  __syncthreads();
+  const SweepParams prm = prm_s;
+  // never read past the pair's own vectors, whatever the host wrote into the state record
+  const size_t n = prm.n < n_pair ? prm.n : n_pair;
+  block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, first, n, prm, wave_out, raw_s);
+#ifdef SBA_STEP_PROFILE
+  tk[3] = wall_clock64();
+#endif
+  if (KIND == KIND_FACTORED && MODE != MODE_TRAN) {
+    if (tid == 0) {
+      double pack[24];
+      moments_to_normal_pack(true, MODE == MODE_RT, frame_s, frame_s + 9, raw_s, pack);
+#pragma unroll
+      for (int k = 0; k < 24; ++k) raw_s[k] = pack[k];
+    }
+    __syncthreads();
+  }
+#ifdef SBA_STEP_PROFILE
+  tk[4] = wall_clock64();
+  if (tid == 0) {   // ticks of the 100 MHz clock: state read / state build / sweep + fold / conversion, in pack slots 0..3
+    raw_s[0] = static_cast<double>(tk[1] - tk[0]); raw_s[1] = static_cast<double>(tk[2] - tk[1]);
+    raw_s[2] = static_cast<double>(tk[3] - tk[2]); raw_s[3] = static_cast<double>(tk[4] - tk[3]);
+    raw_s[4] = static_cast<double>(tk[0] % 100000000);
+  }
+  __syncthreads();
+#endif
+  if (tid >= 64) return;                 // wave 0 finishes alone
+  if (tid < 24) {
+    const double v = raw_s[tid];
+    packs[static_cast<size_t>(pair) * 24 + tid] = v;
+    if (packs_host) packs_host[static_cast<size_t>(pair) * 24 + tid] = v;
+  }
+  if (!packs_host) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + static_cast<size_t>(gridDim.x) * 24), seq,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- the whole per-pair solve in ONE launch ---------------------------------------------------------------------
 // With one block per pair (bpp == 1: at least one pair per CU, config C5) a pair's sweep is reduced completely inside
 // its block, so nothing about its Levenberg-Marquardt iteration needs another block -- or the host.  Block g runs pair
@@ -194,8 +314,6 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
                                                          unsigned int* __restrict__ ticket,
                                                          unsigned long long* __restrict__ seq_host,
                                                          unsigned long long seq) {
-  constexpr int NACC = AccMap<MODE, KIND>::N;
-  constexpr int PPT = Lanes<ST>::PPT;
   __shared__ double wave_out[(kBlock / 64) * 24];
   __shared__ double raw_s[24];
   __shared__ SweepParams prm_s;
@@ -206,7 +324,6 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
   const int tid = threadIdx.x;
   const unsigned pair = blockIdx.x;
   const size_t n = desc[pair].n, first = desc[pair].first_vec;
-  const size_t nfull = n / PPT;
   __shared__ double depth_s[2];
   if (tid == 0) {
     // io lives in mapped HOST memory: one read of the pair's record here, one write of its result at the end
@@ -221,12 +338,31 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
 #else
 #define SBA_TICK(acc) do { } while (0)
 #endif
+  // ONE thread-0 region per iteration, directly in front of the loop's first barrier: it consumes the previous sweep's
+  // sums (if any), then publishes either "done" or the next sweep state.  (Two thread-0 regions either side of the
+  // back edge -- feed at the bottom, prepare at the top -- invite the compiler to thread them into a private inner loop
+  // for the other 255 threads, whose barrier then runs without lane 0: tests/test_isa_checks_cpu.py guards the shape.)
+  // evals_left bounds the loop independently of the solver (which needs at most max_num_iterations + 1 evaluations).
+  bool have_sums = false;
+  int evals_left = opt.max_num_iterations + 8;
   for (;;) {
     if (tid == 0) {
 #ifdef SBA_LM_PROFILE
       tk0 = wall_clock64();
 #endif
-      done_s = solver->done() ? 1 : 0;
+      if (have_sums) {
+        double pack[24];
+        if (KIND == KIND_FACTORED && MODE != MODE_TRAN)
+          moments_to_normal_pack(true, MODE == MODE_RT, frame_s, frame_s + 9, raw_s, pack);
+        else
+          for (int k = 0; k < 24; ++k) pack[k] = raw_s[k];
+        sba_normal_eq ne;
+        expand_pack(MODE, pack, &ne);
+        SBA_TICK(tk_conv);
+        solver->feed(ne);
+        SBA_TICK(tk_feed);
+      }
+      done_s = (solver->done() || evals_left-- <= 0) ? 1 : 0;
       if (!done_s) {
         fill_sweep_params(n, DEPTH, solver->query_rot(), solver->query_tran(), depth_s[0], depth_s[1], opt.huber_delta, &prm_s,
                           KIND == KIND_EXPLICIT);
@@ -237,53 +373,11 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     __syncthreads();
     if (done_s) break;
     const SweepParams prm = prm_s;        // LDS broadcast -> registers, held across the sweep
-    double acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-    size_t p = tid;
-    VecRegs<ST, DEPTH> cur, nxt;
-    if (p < nfull) cur.load(pl, first + p);
-    while (p < nfull) {
-      const size_t pn = p + kBlock;
-      if (pn < nfull) nxt.load(pl, first + pn);
-      consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, &prm, p, n, acc);
-      cur = nxt;
-      p = pn;
-    }
-    if (nfull * PPT != n && tid == kBlock - 1) {
-      cur.load(pl, first + nfull);
-      consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, &prm, nfull, n, acc);
-    }
-    const int lane = tid & 63, wave = tid >> 6;
-    if (tid < 24) raw_s[tid] = 0.0;       // slots no accumulator maps to stay zero
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-      const double sw = wave_sum_to_lane63(acc[k]);
-      if (lane == 63) wave_out[wave * 24 + AccMap<MODE, KIND>::slot(k)] = sw;
-    }
-    __syncthreads();
-    if (tid < NACC) {
-      const int slot = AccMap<MODE, KIND>::slot(tid);
-      double sum = wave_out[slot];
-#pragma unroll
-      for (int wv = 1; wv < kBlock / 64; ++wv) sum += wave_out[wv * 24 + slot];     // same fold order as the 3-kernel path
-      raw_s[slot] = sum;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      SBA_TICK(tk_sweep);
-      double pack[24];
-      if (KIND == KIND_FACTORED && MODE != MODE_TRAN)
-        moments_to_normal_pack(true, MODE == MODE_RT, frame_s, frame_s + 9, raw_s, pack);
-      else
-        for (int k = 0; k < 24; ++k) pack[k] = raw_s[k];
-      sba_normal_eq ne;
-      expand_pack(MODE, pack, &ne);
-      SBA_TICK(tk_conv);
-      solver->feed(ne);
-      SBA_TICK(tk_feed);
-    }
-    // thread 0 re-enters the loop head alone; everybody else waits at its barrier
+    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, first, n, prm, wave_out, raw_s);
+    have_sums = true;
+#ifdef SBA_LM_PROFILE
+    if (tid == 0) SBA_TICK(tk_sweep);
+#endif
   }
   if (tid == 0) {
     BatchLmIo res;
@@ -295,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     res.summary.initial_cost = static_cast<double>(tk_prep); res.summary.final_cost = static_cast<double>(tk_sweep);
     res.summary.final_gradient_max_norm = static_cast<double>(tk_conv); res.summary.final_radius = static_cast<double>(tk_feed);
 #endif
-    res.status = solver->status();
+    res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // evals_left ran out: cannot happen, but never silent
     res.pad_ = 0;
     io[pair] = res;
     // Completion: this block's record is in host memory (system-scope release + vmcnt(0)) before it takes a ticket; the
@@ -367,7 +461,45 @@ BatchLmFn lpick(int mode, int depth, int store, int kind, bool loss) {
   return nullptr;
 }
 
+typedef void (*BatchStepFn)(Planes, const PairDesc*, const BatchState*, double, double*, double*, unsigned int*,
+                            unsigned long long);
+template <int MODE, int DEPTH, typename ST, int KIND>
+BatchStepFn spick_loss(bool loss) {
+  return loss ? batch_step_kernel<MODE, DEPTH, ST, KIND, true> : batch_step_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+BatchStepFn spick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? spick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss)
+                               : spick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
+template <int MODE, int DEPTH>
+BatchStepFn spick_store(int store, int kind, bool loss) {
+  return store == 0 ? spick_kind<MODE, DEPTH, double>(kind, loss) : spick_kind<MODE, DEPTH, float>(kind, loss);
+}
+BatchStepFn spick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return spick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return spick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return spick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return spick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return spick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return spick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
+}
+
 }  // namespace
+
+hipError_t launch_batch_step_fused(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
+                                   const BatchState* state, const PairDesc* desc, int num_pairs, double* packs,
+                                   double* packs_host, unsigned int* ticket, unsigned long long seq, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchStepFn fn = spick(mode, depth, store, kind, huber_delta > 0.0);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs)), dim3(kBlock), 0, stream, pl, desc, state, huber_delta,
+                     packs, packs_host, ticket, seq);
+  return hipGetLastError();
+}
 
 hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
                            BatchLmIo* io, const sba_lm_options& opt, int num_pairs, unsigned int* ticket,

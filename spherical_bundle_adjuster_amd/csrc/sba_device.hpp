@@ -121,6 +121,13 @@ struct BatchState {
   unsigned long long pad_;
 };
 static_assert(sizeof(BatchState) == 80, "BatchState is copied word by word");
+// The same step in ONE launch, for batches with one block per pair (bpp == 1): every block prepares its own pair's
+// state, sweeps, folds, converts and publishes its pack; the last one stores `seq` at packs_host[24 * num_pairs].
+// ticket: one zeroed device word.
+hipError_t launch_batch_step_fused(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
+                                   const BatchState* state, const PairDesc* desc, int num_pairs, double* packs,
+                                   double* packs_host, unsigned int* ticket, unsigned long long seq, hipStream_t stream);
+
 // In / out record of one pair for the one-launch per-pair solve (batch_lm_kernel): start point and uniform depths in,
 // result, summary and status out.
 struct BatchLmIo {

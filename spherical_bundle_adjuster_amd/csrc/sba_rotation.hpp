@@ -31,6 +31,13 @@
 #define SBA_HD
 #endif
 
+// No FMA contraction in here: the per-sweep state and the moment -> normal-equation map are evaluated in several
+// compilations (host g++, host clang, several device kernels with the flags known at compile time or not); with
+// contraction left to the optimiser their last bits differ from one instantiation to the next.
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT OFF
+#endif
+
 namespace sba {
 
 // a = sin(th)/th, b = (1-cos th)/th^2, c = (th - sin th)/th^3, ap = (da/dth)/th, bp = (db/dth)/th.
@@ -170,3 +177,7 @@ SBA_HD inline void moments_to_normal_pack(bool rot_free, bool tran_free, const d
 }
 
 }  // namespace sba
+
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT DEFAULT
+#endif

@@ -1,6 +1,7 @@
 """GPU (-m gpu): batched per-pair sweeps and LM (BASELINE config C5 shape, scaled down) against per-pair oracle /
 single-problem results; ragged and empty pairs; both kernels; equi2cube on a batch of frames."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -82,6 +83,17 @@ def test_batch_config_c5_full_size_properties(oracle):
         assert np.array_equal(p1, b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH))
         ms = b.sweep_launch_times(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, repeat=5)
         assert ms.shape == (5,) and (ms > 0).all()
+        # one block per pair: the step is ONE launch (batch_step_kernel); the three-kernel chain gives the same bits
+        assert b.blocks_per_pair == 1 and b.step_is_fused
+        ms = b.step_launch_times(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, repeat=5)
+        assert ms.shape == (5,) and (ms > 0).all()
+        assert np.array_equal(p1, b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH))
+        os.environ["SBA_BATCH_FUSED_STEP"] = "0"
+        try:
+            assert not b.step_is_fused
+            assert np.array_equal(p1, b.eval(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH))
+        finally:
+            del os.environ["SBA_BATCH_FUSED_STEP"]
         rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
                                           options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
         assert (status == 0).all() and all(s.termination.startswith("CONVERGENCE") for s in sums)
@@ -102,6 +114,70 @@ def test_batch_config_c5_full_size_properties(oracle):
                  np.concatenate([cs[g].d12 for g in order]))
         p2 = b.eval(api.MODE_RT, rot0[order], tran0[order], depth_mode=api.DEPTH_PER_MATCH)
     assert np.array_equal(p2[::-1], p1)
+
+
+@pytest.mark.parametrize("kind", [api.KERNEL_FACTORED, api.KERNEL_EXPLICIT], ids=["factored", "explicit"])
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+def test_one_block_per_pair_paths_equal_the_chain_and_the_oracle(oracle, kind, store):
+    """Many small ragged pairs get one block each, which switches on the two one-launch paths: batch_step_kernel (a whole
+    evaluation step) and batch_lm_kernel (a whole per-pair solve).  Both must give the numbers of the general paths -- the
+    three-kernel chain and the host lock-step LM (to the last bit or two) -- for every mode, depth mode, kernel and plane type, and the oracle's
+    numbers per pair (empty, 1-match and ragged-tail pairs included)."""
+    sizes = [0, 1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 500, 511, 512] + [17 * g % 509 for g in range(30)]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=12000)
+    B = len(sizes)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    d1 = np.linspace(0.8, 1.7, B); d2 = np.linspace(1.3, 0.6, B)
+    with api.Batch(0) as b:
+        b.set_kernel(kind)
+        b.upload(x1, x2, off, d12, store=store)
+        assert b.blocks_per_pair == 1 and b.step_is_fused
+        for mode in (api.MODE_ROT, api.MODE_TRAN, api.MODE_RT):
+            for dm in (api.DEPTH_PER_MATCH, api.DEPTH_UNIFORM):
+                for delta in (1.0, 0.0):
+                    fused = b.eval(mode, rot0, tran0, d1, d2, delta, dm)
+                    os.environ["SBA_BATCH_FUSED_STEP"] = "0"
+                    try:
+                        chain = b.eval(mode, rot0, tran0, d1, d2, delta, dm)
+                    finally:
+                        del os.environ["SBA_BATCH_FUSED_STEP"]
+                    # same sums in the same fold order; the two kernels are separate instantiations of the sweep core,
+                    # and the compiler's FMA contraction of a ragged tail may differ between them in the last bit
+                    assert np.abs(fused - chain).max() <= 1e-15 * max(np.abs(chain).max(), 1e-300), (mode, dm, delta)
+                for g in (0, 1, 4, 9, 13, 20):
+                    c = cs[g]
+                    a1, a2 = ((c.x1, c.x2) if store == api.STORE_F64 else
+                              (c.x1.astype(np.float32).astype(np.float64), c.x2.astype(np.float32).astype(np.float64)))
+                    ref = pack_from_eval(mode, oracle.evaluate(mode, a1, a2, c.rot_init, c.tran_init, d1[g], d2[g], 0.0,
+                                                               c.d12 if dm == api.DEPTH_PER_MATCH else None))
+                    scale = max(np.abs(ref).max(), 1e-300)
+                    assert np.abs(fused[g] - ref).max() <= REL_TOL_F64 * scale, (mode, dm, g, sizes[g])
+        # the whole solve in one launch against the host lock-step loop (same LmSolver source, same sums: same bits)
+        for mode, tp in ((api.MODE_RT, api.TRAN_SPHERE), (api.MODE_ROT, api.TRAN_FREE), (api.MODE_TRAN, api.TRAN_FREE)):
+            opt = api.default_lm_options(tran_param=tp)
+            dev = b.solve(mode, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, options=opt)
+            os.environ["SBA_BATCH_DEVICE_LM"] = "0"
+            try:
+                host = b.solve(mode, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, options=opt)
+            finally:
+                del os.environ["SBA_BATCH_DEVICE_LM"]
+            assert np.array_equal(dev[3], host[3])
+            for g in range(B):
+                sd, sh = dev[2][g], host[2][g]
+                if sizes[g] == 0:
+                    assert np.array_equal(dev[0][g], rot0[g]) and sd.num_evaluations == 1
+                if sizes[g] < 50:        # under-determined toys: sin / cos differ in the last bit between host and device,
+                    continue             # which such problems may amplify into another iteration count
+                assert (sd.num_iterations, sd.num_successful_steps, sd.num_evaluations, sd.termination) == \
+                       (sh.num_iterations, sh.num_successful_steps, sh.num_evaluations, sh.termination), (mode, g, sizes[g])
+                assert np.abs(dev[0][g] - host[0][g]).max() <= 1e-12 and np.abs(dev[1][g] - host[1][g]).max() <= 1e-12, (mode, g)
+            if store == api.STORE_F64:
+                for g in (11, 12, 13):
+                    c = cs[g]
+                    ro, to, so, rc = oracle.lm_solve(mode, c.x1, c.x2, c.rot_init, c.tran_init, d12=c.d12,
+                                                     options=oracle.default_options(tran_param=tp))
+                    assert rc == 0 and dev[2][g].num_iterations == so.num_iterations
+                    assert np.abs(dev[0][g] - ro).max() <= RT_TOL_F64 and np.abs(dev[1][g] - to).max() <= RT_TOL_F64
 
 
 def test_equi2cube_512_frames_device_resident():

@@ -1,0 +1,94 @@
+"""CPU: shape checks on the generated gfx950 code of the one-launch per-pair LM kernel (no GPU needed: hipcc cross-compiles).
+
+batch_lm_kernel is a block-wide loop -- thread 0 prepares, barrier, all threads sweep, barrier, fold, barrier -- whose
+correctness needs every barrier to be executed by all 256 threads of the block in the same trip of the SAME loop.  The
+compiler once threaded a thread-0 region at the bottom of the loop into the one at its top, which left the other 255
+threads in a private inner loop: their barrier ran without lane 0 (lane 0 waits for the inner loop to end under the
+structured-control-flow lowering) and the kernel never finished.  The check: in every instantiation, each s_barrier sits
+in loop depth exactly 1, there are exactly three of them, and nothing of the kernel spills beyond the solver's 320-byte
+scratch frame.  The one-launch step kernel (no loop around its barriers) must have its barriers at depth 0."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "spherical_bundle_adjuster_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def batch_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "sba_batch_kernels.s"
+    hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                    os.path.join(CSRC, "sba_batch_kernels.hip"), "-o", str(out)], check=True, capture_output=True, cwd=CSRC)
+    return out.read_text()
+
+
+def _functions(asm):
+    """name -> list of body lines (label line to s_endpgm)."""
+    funcs, name, body = {}, None, []
+    for line in asm.splitlines():
+        m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
+        if m and name is None:
+            name, body = m.group(1), []
+            continue
+        if name is not None:
+            body.append(line)
+            if "s_endpgm" in line:
+                funcs[name] = body
+                name = None
+    return funcs
+
+
+def _barrier_depths(body):
+    """Loop depth of each s_barrier: the depth LLVM's asm printer annotates on the enclosing basic block."""
+    depths, depth, in_header = [], 0, False
+    for line in body:
+        s = line.strip()
+        is_label = re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", s) is not None
+        if is_label:
+            m = re.search(r"Depth=(\d+)", s)
+            depth = int(m.group(1)) if m else 0
+            in_header = True
+            continue
+        if in_header and s.startswith(";"):            # continuation of a loop-header comment: innermost depth wins
+            m = re.search(r"Depth=(\d+)", s)
+            if m:
+                depth = max(depth, int(m.group(1)))
+            continue
+        in_header = False
+        if s.startswith("s_barrier"):
+            depths.append(depth)
+    return depths
+
+
+def test_lm_kernel_barriers_are_block_uniform(batch_asm):
+    funcs = _functions(batch_asm)
+    lm = {k: v for k, v in funcs.items() if "batch_lm_kernel" in k}
+    assert len(lm) >= 20, len(lm)            # modes x depth x store x kind x loss instantiations
+    for name, body in lm.items():
+        d = _barrier_depths(body)
+        assert d == [1, 1, 1], (name, d)
+
+
+def test_step_kernel_barriers_outside_loops(batch_asm):
+    funcs = _functions(batch_asm)
+    st = {k: v for k, v in funcs.items() if "batch_step_kernel" in k}
+    assert len(st) >= 20, len(st)
+    for name, body in st.items():
+        d = _barrier_depths(body)
+        assert d and all(x == 0 for x in d), (name, d)
+
+
+def test_lm_kernel_scratch_is_the_solver_frame_only(batch_asm):
+    sizes = {}
+    for m in re.finditer(r"\.name:\s+(\S*batch_lm_kernel\S*)\n(?:.*\n){0,40}?\s+\.private_segment_fixed_size:\s+(\d+)", batch_asm):
+        sizes[m.group(1)] = int(m.group(2))
+    assert sizes, "no kernel metadata found"
+    assert max(sizes.values()) <= 512, sizes
