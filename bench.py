@@ -207,6 +207,7 @@ def run_c5(a):
         # pair, batch_sweep_kernel otherwise
         fused = b.step_is_fused
         per_launch = b.step_launch_times(api.MODE_RT, rot0, tran0, repeat=max(a.steps, 20), **kw)
+        sweep_alone = b.sweep_launch_times(api.MODE_RT, rot0, tran0, repeat=max(a.steps, 20), **kw) if fused else per_launch
         # per-pair LM: all pairs solved in lock-step off the batched launches
         opt = api.default_lm_options(tran_param=api.TRAN_SPHERE)
         b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
@@ -259,7 +260,11 @@ def run_c5(a):
                          "kernel_ms_what": f"mean of {len(per_launch)} launches, HIP event between every two",
                          "kernel_ms_min": float(per_launch.min()), "kernel_ms_median": float(np.median(per_launch)),
                          "kernel_ms_max": float(per_launch.max()),
-                         "algorithmic_bytes_per_launch": B * n * 64},
+                         "algorithmic_bytes_per_launch": B * n * 64,
+                         # the streaming part on its own (the chain's sweep kernel: no state build, fold to rows only)
+                         "sweep_kernel_alone": {"kernel": "batch_sweep_kernel<2, 1, double, 0, true>",
+                                                "kernel_ms": float(sweep_alone.mean()),
+                                                "frac": B * n * 64 / (float(sweep_alone.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBPS}},
             "preconditioning": {**precond, "what": "un-timed launches of the same kernel before the warm-up steps"},
             "step_split_ms": split,
             "lm": {"pairs_per_s": B / lm_s, "seconds": lm_s, "seconds_inside_the_library": max(s_.seconds_total for s_ in sums),
