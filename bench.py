@@ -68,6 +68,8 @@ def parse():
                          "the shim: what north_star names) and, only if RCCL cannot be set up on every rank, the "
                          "torch.distributed hook; rccl = RCCL or fail; peer = direct xGMI exchange (opt-in)")
     ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
+    ap.add_argument("--no-peer-trial", action="store_true",
+                    help="N > 1: skip the second, un-quoted measurement over the direct xGMI peer exchange")
     return ap.parse_args()
 
 
@@ -306,6 +308,63 @@ def pmc_traffic_named(kernel_prefix: str, units: int):
     return None
 
 
+def peer_trial(p, transport, dist, torch, run_steps, barrier, ref_pack, world, n):
+    """N > 1, after the quoted measurement: the same K steps over the direct xGMI peer exchange (tools: DESIGN.md 5).
+    Never the quoted `value`; it exists so that the first multi-GPU run also says what one-launch peer stores cost
+    next to the RCCL all-reduce.  Every rank goes through the same control collectives whatever fails locally
+    (distributed._all_agree after every phase), and every device-side wait of the peer kernel is bounded in time."""
+    import numpy as np
+    from spherical_bundle_adjuster_amd import distributed
+    res = {"ok": False, "what": "same shard, same K host-synchronous steps, all-reduce by direct peer stores over xGMI "
+                                "(one launch per step: fold + exchange + publication); not the quoted value"}
+
+    def phase(name, fn):
+        ok = True
+        try:
+            fn()
+        except Exception as e:          # noqa: BLE001 -- recorded, and agreed on below
+            ok = False
+            res.setdefault("errors", []).append(f"{name}: {type(e).__name__}: {e}")
+        agreed = distributed._all_agree(torch, dist, ok)
+        if not agreed:
+            res.setdefault("failed_phase", name)
+        return agreed
+
+    def detach():
+        if transport == "rccl-native":
+            p.comm_destroy()
+        elif transport == "torch-hook":
+            p.set_allreduce(None)
+        elif transport == "xgmi-peer":
+            p.peer_disable()
+
+    if not phase("detach", detach):
+        return res
+    attached = [False]
+    if not phase("attach", lambda: attached.__setitem__(0, distributed._try_peer(p, torch, dist))) or not attached[0]:
+        res.setdefault("failed_phase", "attach")
+        return res
+    out = {}
+    if not phase("warmup", lambda: run_steps(5)):
+        return res
+    barrier()
+
+    def timed():
+        t0 = time.perf_counter()
+        out["pack"], out["steps"] = run_steps(None)
+        out["elapsed"] = time.perf_counter() - t0
+    if not phase("steps", timed):
+        return res
+    barrier()
+    t = torch.tensor([out["elapsed"]], dtype=torch.float64, device=distributed._ctrl_device(torch, dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    scale = max(float(np.abs(ref_pack).max()), 1e-300)
+    res.update(ok=True, ms_per_step=elapsed / out["steps"] * 1e3, value=n * world * out["steps"] / elapsed,
+               max_rel_diff_to_quoted_pack=float(np.abs(out["pack"] - ref_pack).max() / scale))
+    return res
+
+
 def main():
     a = parse()
     if a.workload == "c5":
@@ -402,6 +461,12 @@ def main():
     p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)         # first call: one-time costs
     r_s, t_s, summ = p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)
     barrier()
+    trial = None
+    if world > 1 and not a.no_peer_trial and os.environ.get("SBA_BENCH_PEER_TRIAL", "1") != "0":
+        def run_steps(k):
+            k = a.steps if k is None else k
+            return p.eval_steps(mode, rot, tran, depth_mode=depth_mode, steps=k)[0], k
+        trial = peer_trial(p, transport, dist, torch, run_steps, barrier, pack, world, a.n)
 
     if rank == 0:
         total = a.n * world
@@ -442,6 +507,7 @@ def main():
                    "iterations": summ.num_iterations, "termination": summ.termination,
                    "rot_err_rad": float(np.abs(r_s - c.rot_true).max()),
                    "tran_err": float(np.abs(t_s - c.tran_true).max())},
+            "peer_trial": trial,
             "upload_s": upload_s,   # once per problem (H2D over PCIe + re-layout); never part of `value`
             "pcie_inclusive_evals_per_s_if_reuploaded_every_sweep": a.n / (upload_s + elapsed / a.steps),
             "cost": float(pack[22]),

@@ -145,6 +145,9 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     assert b["lm"]["termination"].startswith("CONVERGENCE") and "cpu_baseline" not in b
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in b["roofline"]
+    # the second, un-quoted measurement over the peer exchange (detach -> attach -> self-test -> K steps) went through
+    t = b["peer_trial"]
+    assert t["ok"] and t["ms_per_step"] > 0 and t["max_rel_diff_to_quoted_pack"] <= 1e-12, t
 
 
 def test_bench_c5_two_rank_rehearsal(tmp_path):
