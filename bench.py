@@ -10,6 +10,8 @@ correspondences with per-match depths (64 algorithmic bytes per evaluation: 2 x 
 components + 2 f64 depths), f64 arithmetic.  At N > 1: one GPU's shard of BASELINE config C4 ("100M
 correspondences sharded 8xMI355X") = 12.5M of the same correspondences per GPU, one RCCL all-reduce of the
 24-double pack per step (the collective north_star names; `--transport peer` selects the direct xGMI exchange).
+At N > 1 the line also carries `peer_trial`: after the quoted measurement, the same K steps once more over the direct
+peer exchange -- a second figure, never the quoted `value` (`--no-peer-trial` skips it).
 A *step* is one pass of the hot path over the resident correspondences exactly as one LM iteration needs it: sweep
 kernel (residual + analytic Jacobian + Huber + reduction), finalize kernel, the all-reduce when N > 1, and the pack
 published to and awaited by the host.  Weak scaling: per-GPU work is fixed as N grows, no data-path communication
