@@ -9,6 +9,24 @@
 
 #include "sba_problem.hpp"
 
+// RCCL is bound at run time (dlopen), so nothing here links against it -- but where its header is installed the
+// hand-declared ABI (enum values, the 128-byte id passed by value, argument lists) is checked against it at compile time.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert(sba::shim::kNcclFloat64 == static_cast<int>(ncclFloat64) && sba::shim::kNcclSum == static_cast<int>(ncclSum),
+              "RCCL enum values changed");
+static_assert(sizeof(ncclUniqueId) == SBA_COMM_ID_BYTES && sizeof(sba::shim::Rccl::UniqueId) == sizeof(ncclUniqueId),
+              "ncclUniqueId is no longer 128 bytes");
+static_assert(std::is_pointer<ncclComm_t>::value && sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) &&
+              sizeof(ncclRedOp_t) == sizeof(int), "RCCL handle / enum representation changed");
+static_assert(std::is_same<decltype(&ncclAllReduce), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t,
+                                                                      ncclComm_t, hipStream_t)>::value,
+              "ncclAllReduce argument list changed");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>::value,
+              "ncclCommInitRank argument list changed");
+#endif
+
 namespace sba {
 namespace shim {
 
