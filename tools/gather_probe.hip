@@ -118,6 +118,97 @@ __global__ __launch_bounds__(256) void gather_pix1x(const int* __restrict__ tabl
     }
   for (; f < f1; ++f) store(out + static_cast<size_t>(f) * out_stride, load(src + static_cast<size_t>(f) * src_stride));
 }
+// decomposition of variant 7 (one pixel per lane, quad-packed stores): MODE 1 = no source loads (table + stores only),
+// MODE 2 = no stores (table + source loads; one never-taken store keeps the loads alive), MODE 3 = neither
+template <int MODE>
+__global__ __launch_bounds__(256) void gather_parts(const int* __restrict__ table, size_t out_pixels, const uint8_t* __restrict__ src,
+                                                    size_t src_stride, uint8_t* __restrict__ out, size_t out_stride, int batch, int fpb) {
+  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool valid = g < out_pixels;
+  const size_t p = valid ? static_cast<size_t>(table[g]) * 3 : 0;
+  const int j = threadIdx.x & 3;
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  uint32_t acc = 0;
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    uint32_t v = static_cast<uint32_t>(p);
+    if (MODE == 0 || MODE == 2) v = uint32_t(sa[p]) | (uint32_t(sa[p + 1]) << 8) | (uint32_t(sa[p + 2]) << 16);
+    if (MODE == 0 || MODE == 1) {
+      const uint32_t nx = __builtin_amdgcn_update_dpp(0u, v, 0xF9, 0xf, 0xf, false);
+      const uint32_t d = (v >> (8 * j)) | (nx << (24 - 8 * j));
+      if (valid && j < 3) reinterpret_cast<uint32_t*>(out + static_cast<size_t>(f) * out_stride + (g & ~size_t(3)) * 3)[j] = d;
+    } else {
+      acc += v;
+    }
+  }
+  if ((MODE == 2 || MODE == 3) && acc == 0x12345678u) out[g] = 1;     // practically never
+}
+// variant 13: as 7, but a block covers K x 256 consecutive output pixels: lane t owns pixels t, t + 256, ... (every wave
+// instruction still spans 64 consecutive pixels) and issues the loads of all K pixels (x both frames) before the first store
+template <int K>
+__global__ __launch_bounds__(256) void gather_pixk(const int* __restrict__ table, size_t out_pixels, const uint8_t* __restrict__ src,
+                                                   size_t src_stride, uint8_t* __restrict__ out, size_t out_stride, int batch, int fpb) {
+  const size_t g0 = static_cast<size_t>(blockIdx.x) * (256 * K) + threadIdx.x;
+  const int j = threadIdx.x & 3;
+  size_t p[K]; bool valid[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { valid[k] = g0 + 256 * k < out_pixels; p[k] = valid[k] ? static_cast<size_t>(table[g0 + 256 * k]) * 3 : 0; }
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    uint32_t v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = uint32_t(sa[p[k]]) | (uint32_t(sa[p[k] + 1]) << 8) | (uint32_t(sa[p[k] + 2]) << 16);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const size_t g = g0 + 256 * k;
+      const uint32_t nx = __builtin_amdgcn_update_dpp(0u, v[k], 0xF9, 0xf, 0xf, false);
+      const uint32_t d = (v[k] >> (8 * j)) | (nx << (24 - 8 * j));
+      if (valid[k] && j < 3) reinterpret_cast<uint32_t*>(out + static_cast<size_t>(f) * out_stride + (g & ~size_t(3)) * 3)[j] = d;
+    }
+  }
+}
+// variant 14: one pixel per lane, but the three bytes come from ALIGNED dword loads: dword (o & ~3) always, dword + 4 only
+// for the lanes whose pixel straddles it ((o & 3) > 1), funnel-shifted with v_alignbyte.  SECOND = 0: both always.
+template <int PRED>
+__global__ __launch_bounds__(256) void gather_dw(const int* __restrict__ table, size_t out_pixels, const uint8_t* __restrict__ src,
+                                                 size_t src_stride, int src_pixels, uint8_t* __restrict__ out, size_t out_stride,
+                                                 int batch, int fpb) {
+  const size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool valid = g < out_pixels;
+  const int t = valid ? table[g] : 0;
+  const size_t o = static_cast<size_t>(t) * 3, a = o & ~size_t(3);
+  const uint32_t sh = static_cast<uint32_t>(o & 3);
+  const bool second = (PRED ? sh > 1 : true) && t != src_pixels - 1;      // the last pixel's bytes end with the frame
+  const int j = threadIdx.x & 3;
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    const uint32_t lo = *reinterpret_cast<const uint32_t*>(sa + a);
+    uint32_t hi = 0;
+    if (second) hi = *reinterpret_cast<const uint32_t*>(sa + a + 4);
+    const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh) & 0xffffffu;
+    const uint32_t nx = __builtin_amdgcn_update_dpp(0u, v, 0xF9, 0xf, 0xf, false);
+    const uint32_t d = (v >> (8 * j)) | (nx << (24 - 8 * j));
+    if (valid && j < 3) reinterpret_cast<uint32_t*>(out + static_cast<size_t>(f) * out_stride + (g & ~size_t(3)) * 3)[j] = d;
+  }
+}
+// variant 7 restricted to one cube face (face < 0: all): where does the time go, equatorial faces or polar ones?
+__global__ __launch_bounds__(256) void gather_face(const int* __restrict__ table, int S, int face, const uint8_t* __restrict__ src,
+                                                   size_t src_stride, uint8_t* __restrict__ out, size_t out_stride, int batch, int fpb) {
+  // blockIdx.x walks the face's pixels: S rows x S columns, 256 per block along the row-major face
+  const size_t q = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool valid = q < static_cast<size_t>(S) * S;
+  const size_t g = valid ? (q / S) * (6 * static_cast<size_t>(S)) + face * static_cast<size_t>(S) + q % S : 0;
+  const size_t p = static_cast<size_t>(table[g]) * 3;
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+    const uint32_t v = uint32_t(sa[p]) | (uint32_t(sa[p + 1]) << 8) | (uint32_t(sa[p + 2]) << 16);
+    uint8_t* d = out + static_cast<size_t>(f) * out_stride + g * 3;
+    if (valid) { d[0] = uint8_t(v); d[1] = uint8_t(v >> 8); d[2] = uint8_t(v >> 16); }
+  }
+}
 // variant 9: entries sorted by SOURCE index (lanes of a wave read neighbouring source pixels: few lines per load
 // instruction even on the polar faces), scattered 3-byte stores to out[dst[k]]
 __global__ __launch_bounds__(256) void gather_sorted(const int2* __restrict__ pairs, size_t out_pixels, const uint8_t* __restrict__ src,
@@ -163,6 +254,123 @@ __global__ __launch_bounds__(256) void gather_lds(const int* __restrict__ table,
   }
 }
 
+// variant 10: 2-D output tiles (TW x TH = 256 pixels, one per lane).  The host derives per tile the bounding box of its
+// source pixels; the block copies that box (rows of 16-byte chunks, coalesced) into LDS and gathers the three bytes of
+// every pixel from there; tiles whose box exceeds the LDS budget (pole centres, the phi = 0 seam, face borders) gather
+// from global memory as variant 7 does.  hdr[tile] = {first byte of the box (16-aligned), rows, bytes per row, staged?}
+struct TileHdr { unsigned base; unsigned short rows, rowbytes; unsigned staged, pad; };
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void gather_tiled(const TileHdr* __restrict__ hdr, const unsigned short* __restrict__ t16,
+                                                    const int* __restrict__ t32, int tiles_x, int out_w, int out_h,
+                                                    const uint8_t* __restrict__ src, size_t src_stride, int src_pitch,
+                                                    uint8_t* __restrict__ out, size_t out_stride, int batch, int fpb,
+                                                    int lds_per_frame) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tile = blockIdx.x, t = threadIdx.x;
+  const TileHdr h = hdr[tile];
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int orow = ty * TH + t / TW, ocol = tx * TW + t % TW;
+  const bool active = t < TW * TH && ocol < out_w && orow < out_h;   // partial tiles at the right / bottom edge
+  const size_t g = static_cast<size_t>(orow) * out_w + ocol;          // output pixel (strip is row-major, out_w = 6 S)
+  const int j = t & 3;
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  auto store = [&](uint8_t* base, uint32_t v) {
+    const uint32_t nx = __builtin_amdgcn_update_dpp(0u, v, 0xF9, 0xf, 0xf, false);
+    const uint32_t d = (v >> (8 * j)) | (nx << (24 - 8 * j));
+    if (active && j < 3) reinterpret_cast<uint32_t*>(base + (g & ~size_t(3)) * 3)[j] = d;
+  };
+  if (!h.staged) {
+    const size_t p = active ? static_cast<size_t>(t32[static_cast<size_t>(tile) * 256 + t]) * 3 : 0;
+    for (int f = f0; f < f1; ++f) {
+      const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+      store(out + static_cast<size_t>(f) * out_stride, uint32_t(sa[p]) | (uint32_t(sa[p + 1]) << 8) | (uint32_t(sa[p + 2]) << 16));
+    }
+    return;
+  }
+  // copy the box: lanes are dealt (row, chunk) pairs, cpr2 = chunks per row rounded up to a power of two
+  const int cpr = h.rowbytes >> 4;
+  int sh = 0; while ((1 << sh) < cpr) ++sh;
+  const int rows_per_pass = 256 >> sh;
+  const int k = t & ((1 << sh) - 1), r0 = t >> sh;
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride + h.base;
+    uint8_t* l = lds + (f - f0) * lds_per_frame;
+    if (k < cpr)
+      for (int r = r0; r < h.rows; r += rows_per_pass)
+        *reinterpret_cast<uint4*>(l + r * h.rowbytes + k * 16) = *reinterpret_cast<const uint4*>(sa + static_cast<size_t>(r) * src_pitch + k * 16);
+  }
+  __syncthreads();
+  const int off = active ? t16[static_cast<size_t>(tile) * 256 + t] : 0;
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* l = lds + (f - f0) * lds_per_frame + off;
+    store(out + static_cast<size_t>(f) * out_stride, uint32_t(l[0]) | (uint32_t(l[1]) << 8) | (uint32_t(l[2]) << 16));
+  }
+}
+
+template <int TW, int TH>
+int run_tiled(const std::vector<int>& ht, int S, int H, int W, int F, int iters, const uint8_t* src, size_t srcb, uint8_t* out,
+              const uint8_t* ref, size_t outb, int budget) {
+  static_assert(TW * TH <= 256 && TW % 4 == 0, "tile shape");
+  const int out_w = 6 * S, tiles_x = (out_w + TW - 1) / TW, tiles_y = (S + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+  std::vector<TileHdr> hh(ntiles);
+  std::vector<unsigned short> h16(size_t(ntiles) * 256);
+  std::vector<int> h32(size_t(ntiles) * 256);
+  size_t staged = 0, lds_max = 0; double box_bytes = 0;
+  for (int ty = 0; ty < tiles_y; ++ty)
+    for (int tx = 0; tx < tiles_x; ++tx) {
+      const int tile = ty * tiles_x + tx;
+      int rmin = H, rmax = -1, cmin = W, cmax = -1;
+      for (int t = 0; t < TW * TH; ++t) {
+        const int orow = ty * TH + t / TW, ocol = tx * TW + t % TW;
+        if (orow >= S || ocol >= out_w) { h32[size_t(tile) * 256 + t] = -1; continue; }
+        const int idx = ht[size_t(orow) * out_w + ocol];
+        h32[size_t(tile) * 256 + t] = idx;
+        rmin = std::min(rmin, idx / W); rmax = std::max(rmax, idx / W); cmin = std::min(cmin, idx % W); cmax = std::max(cmax, idx % W);
+      }
+      const long long b0 = (static_cast<long long>(rmin) * W * 3 + cmin * 3) & ~15ll;        // W * 3 % 16 == 0 here
+      const long long rowstart = static_cast<long long>(rmin) * W * 3;
+      const int rowbytes = static_cast<int>((((rowstart + cmax * 3 + 3) - b0) + 15) & ~15ll), rows = rmax - rmin + 1;
+      TileHdr h{static_cast<unsigned>(b0), static_cast<unsigned short>(rows), static_cast<unsigned short>(rowbytes), 0, 0};
+      const long long end = b0 + static_cast<long long>(rows - 1) * W * 3 + rowbytes;
+      if (rows * rowbytes <= budget && rowbytes <= 1024 && end <= static_cast<long long>(srcb)) {
+        h.staged = 1; ++staged; lds_max = std::max<size_t>(lds_max, size_t(rows) * rowbytes); box_bytes += double(rows) * rowbytes;
+        for (int t = 0; t < TW * TH; ++t) {
+          const int idx = h32[size_t(tile) * 256 + t];
+          if (idx < 0) continue;
+          h16[size_t(tile) * 256 + t] = static_cast<unsigned short>((idx / W - rmin) * rowbytes + (rowstart + (idx % W) * 3 - b0));
+        }
+      }
+      hh[tile] = h;
+    }
+  TileHdr* dh; unsigned short* d16; int* d32;
+  CK(hipMalloc(&dh, hh.size() * sizeof(TileHdr))); CK(hipMalloc(&d16, h16.size() * 2)); CK(hipMalloc(&d32, h32.size() * 4));
+  CK(hipMemcpy(dh, hh.data(), hh.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
+  CK(hipMemcpy(d16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(d32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
+  const int lds_per_frame = static_cast<int>((lds_max + 15) & ~size_t(15));
+  std::printf("tile %2dx%2d budget %5d: %zu of %d tiles staged, largest box %zu B, mean box %.0f B (768 B of pixels)\n", TW, TH, budget, staged,
+              ntiles, lds_max, box_bytes / std::max<size_t>(staged, 1));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int fpb : {1, 2, 4}) {
+    const unsigned gy = (F + fpb - 1) / fpb;
+    auto launch = [&]() {
+      hipLaunchKernelGGL((gather_tiled<TW, TH>), dim3(ntiles, gy), dim3(256), size_t(lds_per_frame) * fpb, 0, dh, d16, d32, tiles_x, out_w, S, src,
+                         srcb, W * 3, out, outb, F, fpb, lds_per_frame);
+    };
+    CK(hipMemset(out, 0, outb * F));
+    launch(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int it = 0; it < iters; ++it) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    std::vector<uint8_t> a(outb), b(outb);
+    CK(hipMemcpy(a.data(), out + outb * (F - 1), outb, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), ref + outb * (F - 1), outb, hipMemcpyDeviceToHost));
+    std::printf("  fpb %d tiled %dx%d: %.3f ms / %d frames = %.0f frames/s, %.0f GB/s algorithmic, %s\n", fpb, TW, TH, ms, F, F / (ms * 1e-3),
+                double(F) * S * 6 * S * 6 / (ms * 1e-3) / 1e9, std::memcmp(a.data(), b.data(), outb) == 0 ? "same" : "DIFFERENT");
+  }
+  CK(hipFree(dh)); CK(hipFree(d16)); CK(hipFree(d32));
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int F = argc > 1 ? std::atoi(argv[1]) : 64, iters = argc > 2 ? std::atoi(argv[2]) : 5;
   const int H = 1920, W = 3840, S = 600;
@@ -176,8 +384,8 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   // sorted (source, destination) pairs for variant 9
   int2* pairs;
+  std::vector<int> ht(outpx);
   {
-    std::vector<int> ht(outpx);
     CK(hipMemcpy(ht.data(), table, outpx * 4, hipMemcpyDeviceToHost));
     std::vector<int2> hp(outpx);
     for (size_t i = 0; i < outpx; ++i) hp[i] = make_int2(ht[i], static_cast<int>(i));
@@ -187,6 +395,76 @@ int main(int argc, char** argv) {
   }
   const unsigned gx = (outpx / 4 + 255) / 256;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (argc > 3 && std::strcmp(argv[3], "tiled") == 0) {
+    hipLaunchKernelGGL(gather<0>, dim3(gx, F), dim3(256), 0, 0, table, outpx, src, srcb, H * W, ref, outb, F, 1);
+    hipLaunchKernelGGL((gather_pix1x<false, true>), dim3((outpx + 255) / 256, (F + 1) / 2), dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, 2);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int it = 0; it < iters; ++it)
+      hipLaunchKernelGGL((gather_pix1x<false, true>), dim3((outpx + 255) / 256, (F + 1) / 2), dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, 2);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms0; CK(hipEventElapsedTime(&ms0, e0, e1)); ms0 /= iters;
+    std::printf("baseline variant 7 fpb 2: %.3f ms / %d frames, %.0f GB/s algorithmic\n", ms0, F, double(F) * outpx * 6 / (ms0 * 1e-3) / 1e9);
+    {
+      auto timeit = [&](const char* what, auto&& launch) -> int {
+        launch(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int it = 0; it < iters; ++it) launch();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+        std::printf("%s: %.3f ms / %d frames = %.2f us per frame\n", what, ms, F, ms * 1e3 / F);
+        return 0;
+      };
+      const dim3 grid((outpx + 255) / 256, (F + 1) / 2);
+      if (timeit("parts 0 (all)", [&] { hipLaunchKernelGGL(gather_parts<0>, grid, dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, 2); })) return 1;
+      if (timeit("parts 1 (table + stores, no source loads)", [&] { hipLaunchKernelGGL(gather_parts<1>, grid, dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, 2); })) return 1;
+      if (timeit("parts 2 (table + source loads, no stores)", [&] { hipLaunchKernelGGL(gather_parts<2>, grid, dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, 2); })) return 1;
+      if (timeit("parts 3 (table only)", [&] { hipLaunchKernelGGL(gather_parts<3>, grid, dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, 2); })) return 1;
+      auto check = [&]() -> const char* {
+        std::vector<uint8_t> a(outb), b(outb);
+        if (hipMemcpy(a.data(), out + outb * (F - 1), outb, hipMemcpyDeviceToHost) != hipSuccess) return "copy failed";
+        if (hipMemcpy(b.data(), ref + outb * (F - 1), outb, hipMemcpyDeviceToHost) != hipSuccess) return "copy failed";
+        return std::memcmp(a.data(), b.data(), outb) == 0 ? "same" : "DIFFERENT";
+      };
+      for (int face = 0; face < 6; ++face) {
+        char nm[64];
+        std::snprintf(nm, sizeof nm, "face %d alone (byte stores), fpb 2", face);
+        if (timeit(nm, [&] { hipLaunchKernelGGL(gather_face, dim3((size_t(S) * S + 255) / 256, (F + 1) / 2), dim3(256), 0, 0, table, S, face, src, srcb, out, outb, F, 2); })) return 1;
+      }
+      for (int fpb : {1, 2, 4}) {
+        const unsigned gy = (F + fpb - 1) / fpb;
+        char nm[64];
+        CK(hipMemset(out, 0, outb * F));
+        std::snprintf(nm, sizeof nm, "aligned dwords, both always, fpb %d", fpb);
+        if (timeit(nm, [&] { hipLaunchKernelGGL(gather_dw<0>, dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, table, outpx, src, srcb, H * W, out, outb, F, fpb); })) return 1;
+        std::printf("   %s\n", check());
+        CK(hipMemset(out, 0, outb * F));
+        std::snprintf(nm, sizeof nm, "aligned dwords, second predicated, fpb %d", fpb);
+        if (timeit(nm, [&] { hipLaunchKernelGGL(gather_dw<1>, dim3((outpx + 255) / 256, gy), dim3(256), 0, 0, table, outpx, src, srcb, H * W, out, outb, F, fpb); })) return 1;
+        std::printf("   %s\n", check());
+        if (fpb != 2) continue;
+        CK(hipMemset(out, 0, outb * F));
+        std::snprintf(nm, sizeof nm, "pixk K=2 fpb %d", fpb);
+        if (timeit(nm, [&] { hipLaunchKernelGGL(gather_pixk<2>, dim3((outpx + 511) / 512, gy), dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, fpb); })) return 1;
+        std::printf("   %s\n", check());
+        std::snprintf(nm, sizeof nm, "pixk K=4 fpb %d", fpb);
+        if (timeit(nm, [&] { hipLaunchKernelGGL(gather_pixk<4>, dim3((outpx + 1023) / 1024, gy), dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, fpb); })) return 1;
+        std::printf("   %s\n", check());
+        std::snprintf(nm, sizeof nm, "pixk K=8 fpb %d", fpb);
+        if (timeit(nm, [&] { hipLaunchKernelGGL(gather_pixk<8>, dim3((outpx + 2047) / 2048, gy), dim3(256), 0, 0, table, outpx, src, srcb, out, outb, F, fpb); })) return 1;
+        std::printf("   %s\n", check());
+      }
+      CK(hipMemset(out, 0, outb * F));
+    }
+    for (int budget : {8192}) {
+      if (run_tiled<32, 8>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled<24, 10>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled<40, 6>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled<60, 4>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled<20, 12>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+    }
+    return 0;
+  }
   for (int fpb : {1, 2, 4, 8}) {
     if (fpb > F) break;
     const unsigned gy = (F + fpb - 1) / fpb;
