@@ -430,6 +430,10 @@ int sba_crop_rotated_image_device(int device, void* stream, const void* erp_dev,
 /* Diagnostics: number of outputs of the cached source-index table that were decided on the host; -1 if that table has
  * not been built.  kind 0 = equi2cube (param = cube_size), 1 = crop (param = the bit pattern of the float pitch).   */
 long sba_map_table_host_decided(int device, int kind, int param, int im_height, int im_width);
+/* The tiled form of that table, which the gather kernel stages through LDS: number of 32 x 32 output tiles, how many of
+ * them are staged (the rest gather from global memory), LDS bytes per frame.  0, or -1 if the table is not built.      */
+int sba_map_table_tiles(int device, int kind, int param, int im_height, int im_width, int* tiles, int* staged_tiles,
+                        int* lds_bytes_per_frame);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,8 @@ SIGNATURES = {
     "sba_cube2equi_keypoints_device": (C.c_int, [C.c_int, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "sba_crop_rotated_image_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "sba_map_table_host_decided": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sba_map_table_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
     "sba_equi2cube": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "sba_equi2cube_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
 }

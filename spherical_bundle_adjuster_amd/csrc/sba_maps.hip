@@ -209,6 +209,108 @@ __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ tab
   }
 }
 
+// ---- tiled gather: the source bytes of a 32 x 32 output tile staged through LDS ------------------------------------
+// gather_kernel above is bound by the L1's tag look-ups, not by HBM (rocprofv3, 512 frames 3840x1920 -> S = 600: 0.66
+// TCP accesses per cycle and CU plus 16 % tag-conflict stalls, while HBM moves 12.6 MB + 6.5 MB per frame in 9.6 us =
+// 2 TB/s): three scattered byte loads per pixel cost ~47 look-ups per wave instruction.  Here a block owns a 32 x 32
+// tile of the output and `fpb` frames.  When the table is built the host lists, per tile, the 16-byte chunks of the
+// source frame that hold the tile's pixels (exactly those: no bounding box, so seams, poles and face borders need no
+// special case) and gives every pixel its byte offset into that list.  The block copies the chunks into LDS with one
+// coalesced 16-byte load per lane (one look-up per 64 bytes), then every lane takes the three bytes of its four pixels
+// from LDS.  Four pixels per lane = four times the bytes per memory round trip of a block.  Tiles whose chunk list
+// exceeds the LDS budget fall back to byte loads from global memory inside the same kernel -- in the same 2-D tile order,
+// which by itself is worth most of the gain (the sources of vertically neighbouring output pixels share cache lines:
+// 9.83 us per frame for the row-major pixel-per-lane kernel, 7.14-7.36 us for 32 x 16 / 32 x 32 tiles without staging,
+// 6.64 us with it).
+constexpr int kTileW = 32, kTileH = 32, kTilePx = kTileW * kTileH, kTileLanePx = kTilePx / 256;
+// bytes per frame and tile.  Measured on 256 frames 3840x1920 -> S = 600, two frames per block (profiles/r02_gather_sweep.log):
+// 6 / 8 / 12 / 16 / 24 KiB = 7.35 / 6.64-6.95 / 6.82-7.10 / 8.18 / 8.19 us per frame (31 / 72 / 89 / 94 / 100 % of the
+// tiles staged): a larger budget stages more tiles but leaves fewer blocks per CU.
+constexpr int kTileLdsBudget = 8192;
+struct TileHdr { unsigned first_chunk, chunks; };     // chunks == 0: not staged
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void gather_tiled_kernel(const int* __restrict__ table, const TileHdr* __restrict__ hdr,
+                                                           const unsigned* __restrict__ chunk_list,
+                                                           const unsigned short* __restrict__ lds_offset, unsigned ntiles,
+                                                           int tiles_x, int out_w, int out_h, const uint8_t* __restrict__ src,
+                                                           size_t src_stride, uint8_t* __restrict__ out, size_t out_stride,
+                                                           int batch, int frames_per_block, int lds_per_frame,
+                                                           unsigned total_items, int xcd_aware) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];
+  unsigned item = blockIdx.x;
+  if (xcd_aware) {                      // as gather_kernel: every XCD walks a contiguous run of (frame group, tile) items
+    const unsigned per = (total_items + 7u) / 8u;
+    item = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || item >= total_items) return;
+  } else if (item >= total_items) {
+    return;
+  }
+  const unsigned tile = item % ntiles, group = item / ntiles;
+  const int t = threadIdx.x, j = t & 3;
+  const TileHdr h = hdr[tile];
+  const int ty = static_cast<int>(tile) / tiles_x, tx = static_cast<int>(tile) - ty * tiles_x;
+  const int f0 = static_cast<int>(group) * frames_per_block, f1 = min(batch, f0 + frames_per_block);
+  size_t g[kTileLanePx];
+  bool active[kTileLanePx];
+#pragma unroll
+  for (int m = 0; m < kTileLanePx; ++m) {
+    const int q = t + 256 * m, orow = ty * kTileH + q / kTileW, ocol = tx * kTileW + q % kTileW;
+    active[m] = ocol < out_w && orow < out_h;
+    g[m] = static_cast<size_t>(orow) * out_w + ocol;
+  }
+  auto store = [&](uint8_t* d, uint32_t v, int m) {
+    if (PACK) {          // lanes 0..2 of every quad store one dword each (out_w % 4 == 0: a quad is whole or absent)
+      const uint32_t nx = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xF9, 0xf, 0xf, false));
+      const uint32_t dw = (v >> (8 * j)) | (nx << (24 - 8 * j));
+      if (active[m] && j < 3) reinterpret_cast<uint32_t*>(d + (g[m] & ~static_cast<size_t>(3)) * 3)[j] = dw;
+    } else if (active[m]) {
+      d[g[m] * 3] = static_cast<uint8_t>(v); d[g[m] * 3 + 1] = static_cast<uint8_t>(v >> 8); d[g[m] * 3 + 2] = static_cast<uint8_t>(v >> 16);
+    }
+  };
+  if (h.chunks == 0) {                  // chunk list over budget: bytes straight from global memory
+    size_t p[kTileLanePx];
+    bool inside[kTileLanePx];
+#pragma unroll
+    for (int m = 0; m < kTileLanePx; ++m) {
+      const int idx = active[m] ? table[g[m]] : -1;
+      inside[m] = idx >= 0;
+      p[m] = inside[m] ? static_cast<size_t>(idx) * 3 : 0;
+    }
+    for (int f = f0; f < f1; ++f) {
+      const uint8_t* s = src + static_cast<size_t>(f) * src_stride;
+      uint32_t v[kTileLanePx];
+#pragma unroll
+      for (int m = 0; m < kTileLanePx; ++m)
+        v[m] = inside[m] ? static_cast<uint32_t>(s[p[m]]) | (static_cast<uint32_t>(s[p[m] + 1]) << 8) | (static_cast<uint32_t>(s[p[m] + 2]) << 16) : 0u;
+#pragma unroll
+      for (int m = 0; m < kTileLanePx; ++m) store(out + static_cast<size_t>(f) * out_stride, v[m], m);
+    }
+    return;
+  }
+  const unsigned* list = chunk_list + h.first_chunk;
+  for (unsigned c = t; c < h.chunks; c += 256) {
+    const unsigned byte = list[c];
+    for (int f = f0; f < f1; ++f)
+      *reinterpret_cast<uint4*>(tile_lds + (f - f0) * lds_per_frame + c * 16) =
+          *reinterpret_cast<const uint4*>(src + static_cast<size_t>(f) * src_stride + byte);
+  }
+  unsigned off[kTileLanePx];
+#pragma unroll
+  for (int m = 0; m < kTileLanePx; ++m) off[m] = active[m] ? lds_offset[static_cast<size_t>(tile) * kTilePx + t + 256 * m] : 0xffffu;
+  __syncthreads();
+  for (int f = f0; f < f1; ++f)
+#pragma unroll
+    for (int m = 0; m < kTileLanePx; ++m) {
+      uint32_t v = 0;
+      if (off[m] != 0xffffu) {          // 0xffff: the pixel's source lies outside the image (crop) -> 0
+        const uint8_t* l = tile_lds + (f - f0) * lds_per_frame + off[m];
+        v = static_cast<uint32_t>(l[0]) | (static_cast<uint32_t>(l[1]) << 8) | (static_cast<uint32_t>(l[2]) << 16);
+      }
+      store(out + static_cast<size_t>(f) * out_stride, v, m);
+    }
+}
+
 // ---- key-point maps ---------------------------------------------------------------------------------------------
 // In place on records whose first two floats are pt.x, pt.y.  A record with a sensitive decision is left untouched
 // and listed; the host finishes it from the original coordinates.
@@ -309,7 +411,84 @@ struct Table {
   int* dev = nullptr;
   size_t out_pixels = 0;
   size_t host_decided = 0;    // outputs finished on the host when the table was built
+  // tiled form of the same map (gather_tiled_kernel); tile_hdr == nullptr: not available
+  int out_w = 0, out_h = 0, tiles_x = 0, lds_per_frame = 0;
+  unsigned ntiles = 0, staged_tiles = 0;
+  TileHdr* tile_hdr = nullptr;
+  unsigned* chunk_list = nullptr;
+  unsigned short* lds_offset = nullptr;
 };
+void free_table(Table* t) {
+  for (void* p : {static_cast<void*>(t->dev), static_cast<void*>(t->tile_hdr), static_cast<void*>(t->chunk_list),
+                  static_cast<void*>(t->lds_offset)})
+    if (p) (void)hipFree(p);
+  t->dev = nullptr; t->tile_hdr = nullptr; t->chunk_list = nullptr; t->lds_offset = nullptr;
+}
+
+// The tiled form of a finished source-index table: per 32 x 32 output tile the sorted list of the 16-byte chunks of the
+// source frame that hold its pixels, and per pixel its byte offset into the tile's staged copy of them.  A pixel's three
+// bytes may straddle two chunks; both are then in the list and, being neighbours in memory, neighbours in the list.
+int build_tiles(Table* t, hipStream_t stream) {
+  const int out_w = t->out_w, out_h = t->out_h;
+  if (t->out_pixels == 0) return SBA_OK;
+  std::vector<int> table(t->out_pixels);
+  SBA_TRY_HIP(hipMemcpyAsync(table.data(), t->dev, t->out_pixels * sizeof(int), hipMemcpyDeviceToHost, stream));
+  SBA_TRY_HIP(hipStreamSynchronize(stream));
+  const size_t frame_bytes = static_cast<size_t>(t->key.im_h) * t->key.im_w * 3;
+  size_t budget = kTileLdsBudget;
+  if (const char* e = std::getenv("SBA_GATHER_LDS_BUDGET")) {      // tuning only; 16 .. 32768, offsets are 16-bit
+    const long v = std::atol(e);
+    if (v >= 16 && v <= 32768) budget = static_cast<size_t>(v);
+  }
+  const int tiles_x = (out_w + kTileW - 1) / kTileW, tiles_y = (out_h + kTileH - 1) / kTileH;
+  const size_t ntiles = static_cast<size_t>(tiles_x) * tiles_y;
+  std::vector<TileHdr> hdr(ntiles, TileHdr{0, 0});
+  std::vector<unsigned> chunk_list;
+  std::vector<unsigned short> lds_offset(ntiles * kTilePx, 0xffff);
+  std::vector<unsigned> ids;
+  unsigned staged = 0, lds_max = 0;
+  for (size_t tile = 0; tile < ntiles; ++tile) {
+    const int ty = static_cast<int>(tile / tiles_x), tx = static_cast<int>(tile % tiles_x);
+    ids.clear();
+    for (int q = 0; q < kTilePx; ++q) {
+      const int orow = ty * kTileH + q / kTileW, ocol = tx * kTileW + q % kTileW;
+      if (orow >= out_h || ocol >= out_w) continue;
+      const int idx = table[static_cast<size_t>(orow) * out_w + ocol];
+      if (idx < 0) continue;
+      const size_t o = static_cast<size_t>(idx) * 3;
+      ids.push_back(static_cast<unsigned>(o >> 4));
+      if (((o + 2) >> 4) != (o >> 4)) ids.push_back(static_cast<unsigned>((o + 2) >> 4));
+    }
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    // stage unless the list is over budget, empty (nothing to read), or its last chunk reaches past the frame (the last
+    // frame of a batch must not be read beyond its end)
+    if (ids.empty() || ids.size() * 16 > budget || (static_cast<size_t>(ids.back()) + 1) * 16 > frame_bytes) continue;
+    hdr[tile] = TileHdr{static_cast<unsigned>(chunk_list.size()), static_cast<unsigned>(ids.size())};
+    for (unsigned id : ids) chunk_list.push_back(id * 16u);
+    for (int q = 0; q < kTilePx; ++q) {
+      const int orow = ty * kTileH + q / kTileW, ocol = tx * kTileW + q % kTileW;
+      if (orow >= out_h || ocol >= out_w) continue;
+      const int idx = table[static_cast<size_t>(orow) * out_w + ocol];
+      if (idx < 0) continue;
+      const size_t o = static_cast<size_t>(idx) * 3;
+      const size_t rank = static_cast<size_t>(std::lower_bound(ids.begin(), ids.end(), static_cast<unsigned>(o >> 4)) - ids.begin());
+      lds_offset[tile * kTilePx + q] = static_cast<unsigned short>(rank * 16 + (o & 15));
+    }
+    ++staged;
+    lds_max = std::max<unsigned>(lds_max, static_cast<unsigned>(ids.size() * 16));
+  }
+  t->tiles_x = tiles_x; t->ntiles = static_cast<unsigned>(ntiles); t->staged_tiles = staged; t->lds_per_frame = static_cast<int>(lds_max);
+  if (staged == 0) return SBA_OK;
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->tile_hdr), hdr.size() * sizeof(TileHdr)));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->chunk_list), std::max<size_t>(chunk_list.size(), 1) * sizeof(unsigned)));
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->lds_offset), lds_offset.size() * sizeof(unsigned short)));
+  SBA_TRY_HIP(hipMemcpyAsync(t->tile_hdr, hdr.data(), hdr.size() * sizeof(TileHdr), hipMemcpyHostToDevice, stream));
+  SBA_TRY_HIP(hipMemcpyAsync(t->chunk_list, chunk_list.data(), chunk_list.size() * sizeof(unsigned), hipMemcpyHostToDevice, stream));
+  SBA_TRY_HIP(hipMemcpyAsync(t->lds_offset, lds_offset.data(), lds_offset.size() * sizeof(unsigned short), hipMemcpyHostToDevice, stream));
+  SBA_TRY_HIP(hipStreamSynchronize(stream));        // the host vectors go out of scope
+  return SBA_OK;
+}
 std::mutex g_table_mutex;
 std::list<Table> g_tables;          // most recently used first; a handful of geometries per process
 constexpr size_t kMaxTables = 12;
@@ -317,10 +496,12 @@ constexpr size_t kMaxTables = 12;
 int build_table(const TableKey& key, float pitch_deg, hipStream_t stream, Table* t) {
   t->key = key;
   const int S = key.param;
-  t->out_pixels = key.kind == TABLE_EQUI2CUBE ? static_cast<size_t>(S) * 6 * S : static_cast<size_t>(key.im_h / 4) * key.im_w;
+  t->out_h = key.kind == TABLE_EQUI2CUBE ? S : key.im_h / 4;
+  t->out_w = key.kind == TABLE_EQUI2CUBE ? 6 * S : key.im_w;
+  t->out_pixels = static_cast<size_t>(t->out_h) * t->out_w;
   const size_t padded = (t->out_pixels + 3) / 4 * 4;
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->dev), std::max<size_t>(padded, 4) * sizeof(int)));
-  struct Release { Table* t; bool armed = true; ~Release() { if (armed && t->dev) { (void)hipFree(t->dev); t->dev = nullptr; } } } release{t};
+  struct Release { Table* t; bool armed = true; ~Release() { if (armed) free_table(t); } } release{t};
   SBA_TRY_HIP(hipMemsetAsync(t->dev, 0xff, std::max<size_t>(padded, 4) * sizeof(int), stream));   // padding = -1
   TieBuffers ties;
   int rc = ties.alloc(t->out_pixels, stream);
@@ -363,6 +544,8 @@ int build_table(const TableKey& key, float pitch_deg, hipStream_t stream, Table*
     SBA_TRY_HIP(hipGetLastError());
     SBA_TRY_HIP(hipStreamSynchronize(stream));
   }
+  rc = build_tiles(t, stream);
+  if (rc) return rc;
   release.armed = false;
   return SBA_OK;
 }
@@ -385,7 +568,7 @@ int get_table(const TableKey& key, float pitch_deg, hipStream_t stream, Table* o
     // a table may still be read by a gather enqueued on some stream of its device: drain before freeing
     (void)hipSetDevice(g_tables.back().key.device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(g_tables.back().dev);
+    free_table(&g_tables.back());
     g_tables.pop_back();
     (void)hipSetDevice(key.device);
   }
@@ -397,11 +580,32 @@ int launch_gather(const Table& t, const uint8_t* src, int src_pixels, int batch,
   if (t.out_pixels == 0 || batch <= 0) return SBA_OK;
   const size_t src_stride = static_cast<size_t>(src_pixels) * 3, out_stride = t.out_pixels * 3;
   const unsigned gx = static_cast<unsigned>((t.out_pixels + 255) / 256);
-  const int fpb = batch >= 2 ? 2 : 1;       // measured best: 1 / 2 / 4 / 8 frames per block = 1 080 / 1 150 / 1 130 / 1 045 GB/s
+  int fpb = batch >= 2 ? 2 : 1;       // measured best: 1 / 2 / 4 / 8 frames per block = 1 080 / 1 150 / 1 130 / 1 045 GB/s
+  if (const char* e = std::getenv("SBA_GATHER_FPB")) { const int v = std::atoi(e); if (v >= 1 && v <= 4) fpb = std::min(v, batch); }   // tuning only
   const unsigned gy = static_cast<unsigned>((batch + fpb - 1) / fpb);
   const unsigned long long total = static_cast<unsigned long long>(gx) * gy;
   if (total > 0x7fffff00ull) return set_error(SBA_ERR_INVALID_ARG, "batch of %d frames is too large for one launch", batch);
   static const int xcd_aware = [] { const char* e = std::getenv("SBA_GATHER_XCD"); return e && e[0] == '0' ? 0 : 1; }();
+  // The tiled kernel reads 16-byte chunks at frame + 16 k: frames must start on 16-byte boundaries.  SBA_GATHER_TILED=0
+  // keeps the pixel-per-lane kernel (A/B measurements).
+  const char* tiled_env = std::getenv("SBA_GATHER_TILED");
+  const bool aligned = reinterpret_cast<uintptr_t>(src) % 16 == 0 && (batch == 1 || src_stride % 16 == 0);
+  if (t.tile_hdr && t.staged_tiles > 0 && aligned && !(tiled_env && tiled_env[0] == '0')) {
+    const unsigned long long items = static_cast<unsigned long long>(t.ntiles) * gy;
+    if (items > 0x7fffff00ull) return set_error(SBA_ERR_INVALID_ARG, "batch of %d frames is too large for one launch", batch);
+    const unsigned tgrid = static_cast<unsigned>((items + 7ull) / 8ull * 8ull);
+    const size_t lds = static_cast<size_t>(t.lds_per_frame) * fpb;
+    if (t.out_w % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0 && out_stride % 4 == 0)
+      hipLaunchKernelGGL((gather_tiled_kernel<true>), dim3(tgrid), dim3(256), lds, stream, t.dev, t.tile_hdr, t.chunk_list, t.lds_offset,
+                         t.ntiles, t.tiles_x, t.out_w, t.out_h, src, src_stride, out, out_stride, batch, fpb, t.lds_per_frame,
+                         static_cast<unsigned>(items), xcd_aware);
+    else
+      hipLaunchKernelGGL((gather_tiled_kernel<false>), dim3(tgrid), dim3(256), lds, stream, t.dev, t.tile_hdr, t.chunk_list, t.lds_offset,
+                         t.ntiles, t.tiles_x, t.out_w, t.out_h, src, src_stride, out, out_stride, batch, fpb, t.lds_per_frame,
+                         static_cast<unsigned>(items), xcd_aware);
+    SBA_TRY_HIP(hipGetLastError());
+    return SBA_OK;
+  }
   const unsigned grid = static_cast<unsigned>((total + 7ull) / 8ull * 8ull);     // whole rounds of the 8 XCDs
   if (t.out_pixels % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0)
     hipLaunchKernelGGL((gather_kernel<true>), dim3(grid), dim3(256), 0, stream, t.dev, t.out_pixels, src, src_stride, out,
@@ -621,6 +825,21 @@ long sba_map_table_host_decided(int device, int kind, int param, int im_height, 
   std::lock_guard<std::mutex> lock(sba::g_table_mutex);
   for (const sba::Table& t : sba::g_tables)
     if (t.key == sba::TableKey{device, kind, param, im_height, im_width}) return static_cast<long>(t.host_decided);
+  return -1;
+}
+
+// The tiled form of that table (diagnostics / tests): number of 32 x 32 output tiles, how many of them are staged through
+// LDS, and the LDS bytes per frame the gather allocates.  Returns 0, or -1 if the table has not been built.
+int sba_map_table_tiles(int device, int kind, int param, int im_height, int im_width, int* tiles, int* staged_tiles,
+                        int* lds_bytes_per_frame) {
+  std::lock_guard<std::mutex> lock(sba::g_table_mutex);
+  for (const sba::Table& t : sba::g_tables)
+    if (t.key == sba::TableKey{device, kind, param, im_height, im_width}) {
+      if (tiles) *tiles = static_cast<int>(t.ntiles);
+      if (staged_tiles) *staged_tiles = static_cast<int>(t.staged_tiles);
+      if (lds_bytes_per_frame) *lds_bytes_per_frame = t.lds_per_frame;
+      return 0;
+    }
   return -1;
 }
 

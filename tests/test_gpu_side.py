@@ -300,3 +300,58 @@ def test_upload_from_device_arrays(oracle):
         ref2 = oracle.evaluate(0, c.x1.astype(np.float32).astype(np.float64), c.x2.astype(np.float32).astype(np.float64),
                                c.rot_init, c.tran_init, 1.2, 0.8)
         assert np.abs(got.H - ref2.H).max() <= 1e-12 * np.abs(ref2.H).max()
+
+
+@pytest.mark.parametrize("H,W,S,F", [(96, 192, 24, 3), (480, 960, 150, 5), (90, 182, 22, 3), (1920, 3840, 600, 2)])
+def test_gather_paths_agree_and_tiles_are_staged(oracle, H, W, S, F):
+    """The remap runs through one of two kernels: 32 x 32 output tiles staged through LDS (frames on 16-byte boundaries),
+    or one pixel per lane straight from global memory (any alignment; SBA_GATHER_TILED=0).  Both must give the oracle's
+    bytes for every frame of a batch -- also when the source pointer or the frame size breaks the 16-byte alignment the
+    tiled kernel needs (then the other kernel runs), and for the crop map with its outside pixels."""
+    import os
+    torch = pytest.importorskip("torch")
+    lib = cabi.load_library()
+    rng = np.random.default_rng(H * 7 + S)
+    frames = rng.integers(0, 256, (F, H, W, 3), dtype=np.uint8)
+    want = np.stack([oracle.equi2cube(frames[f], S, clamp=True)[0] for f in range(F)])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(src_t):
+        dst = torch.zeros((F, S, 6 * S, 3), dtype=torch.uint8, device="cuda")
+        cabi.check(lib, lib.sba_equi2cube_device(0, C.c_void_p(stream), C.c_void_p(src_t.data_ptr()), H, W, S, F,
+                                                 C.c_void_p(dst.data_ptr())))
+        torch.cuda.synchronize()
+        return dst.cpu().numpy()
+
+    src = torch.from_numpy(frames).cuda()
+    assert np.array_equal(run(src), want)
+    tiles, staged, lds = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert lib.sba_map_table_tiles(0, 0, S, H, W, C.byref(tiles), C.byref(staged), C.byref(lds)) == 0
+    assert tiles.value == -(-S // 32) * -(-6 * S // 32) and 0 < staged.value <= tiles.value and 0 < lds.value <= 8192
+    if (H, W) == (1920, 3840):
+        assert staged.value >= 0.6 * tiles.value           # the C5 geometry: most tiles fit the LDS budget
+    os.environ["SBA_GATHER_TILED"] = "0"
+    try:
+        assert np.array_equal(run(src), want)
+    finally:
+        del os.environ["SBA_GATHER_TILED"]
+    # a source that does not start on a 16-byte boundary
+    raw = torch.zeros(frames.size + 64, dtype=torch.uint8, device="cuda")
+    shifted = raw[4:4 + frames.size]
+    shifted.copy_(src.reshape(-1))
+    assert shifted.data_ptr() % 16 != 0
+    assert np.array_equal(run(shifted), want)
+    # the crop map (outside pixels -> 0) for a batch, both kernels
+    for pitch in (-45.0, -90.0, 30.0):
+        wantc = np.stack([oracle.crop_rotated_image(frames[f], pitch) for f in range(F)])
+        for env in (None, "0"):
+            if env is not None:
+                os.environ["SBA_GATHER_TILED"] = env
+            try:
+                dst = torch.zeros((F, H // 4, W, 3), dtype=torch.uint8, device="cuda")
+                cabi.check(lib, lib.sba_crop_rotated_image_device(0, C.c_void_p(stream), C.c_void_p(src.data_ptr()), H, W,
+                                                                  C.c_float(pitch), F, C.c_void_p(dst.data_ptr())))
+                torch.cuda.synchronize()
+                assert np.array_equal(dst.cpu().numpy(), wantc), (pitch, env)
+            finally:
+                os.environ.pop("SBA_GATHER_TILED", None)

@@ -307,6 +307,221 @@ __global__ __launch_bounds__(256) void gather_tiled(const TileHdr* __restrict__ 
   }
 }
 
+// variant 15: PERSISTENT tiled gather, LDS double-buffered.  Blocks are dealt to the XCDs round-robin; XCD x owns the
+// contiguous run of work items [x * per, (x + 1) * per) (item = frame group * ntiles + tile: whole frame groups, tiles in
+// raster order, so the overlapping boxes of neighbouring tiles meet in ONE L2) and its blocks take them in turn.  While a
+// block gathers item i out of one LDS buffer, the global loads of item i + 1's boxes are in flight into registers; they
+// are written to the other buffer afterwards -- one barrier per item.
+template <int TW, int TH, int FPB, int BUDGET>
+__global__ __launch_bounds__(256) void gather_tiled_persistent(const TileHdr* __restrict__ hdr, const unsigned short* __restrict__ t16,
+                                                               const int* __restrict__ t32, int ntiles, int tiles_x, int out_w, int out_h,
+                                                               const uint8_t* __restrict__ src, size_t src_stride, int src_pitch,
+                                                               uint8_t* __restrict__ out, size_t out_stride, int batch, unsigned total_items) {
+  constexpr int M = BUDGET / 16 / 256;                 // 16-byte chunks per thread and frame
+  static_assert(M >= 1 && BUDGET % (16 * 256) == 0, "budget");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][FPB][BUDGET];
+  const int t = threadIdx.x, j = t & 3;
+  const unsigned xcd = blockIdx.x & 7u, nb = gridDim.x >> 3, per = (total_items + 7u) / 8u;
+  const unsigned lo = xcd * per, hi = min(lo + per, total_items);
+  unsigned item = lo + (blockIdx.x >> 3);
+  if (item >= hi) return;
+
+  uint4 regs[FPB][M];
+  TileHdr hn; int offn = 0, idxn = 0;
+  auto prefetch = [&](unsigned it) {
+    const unsigned tile = it % ntiles, fg = it / ntiles;
+    hn = hdr[tile];
+    offn = t16[static_cast<size_t>(tile) * 256 + t];
+    idxn = t32[static_cast<size_t>(tile) * 256 + t];
+    if (!hn.staged) return;
+    const int cpr = hn.rowbytes >> 4;
+    const float inv = 1.0f / static_cast<float>(cpr);
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) {
+      const int frame = static_cast<int>(fg) * FPB + f;
+      const uint8_t* sa = src + static_cast<size_t>(min(frame, batch - 1)) * src_stride + hn.base;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int c = t + 256 * m, r = static_cast<int>((static_cast<float>(c) + 0.5f) * inv), k = c - r * cpr;
+        if (r < hn.rows) regs[f][m] = *reinterpret_cast<const uint4*>(sa + static_cast<size_t>(r) * src_pitch + k * 16);
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+    if (!hn.staged) return;
+    const int cpr = hn.rowbytes >> 4;
+    const float inv = 1.0f / static_cast<float>(cpr);
+#pragma unroll
+    for (int f = 0; f < FPB; ++f)
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int c = t + 256 * m, r = static_cast<int>((static_cast<float>(c) + 0.5f) * inv);
+        if (r < hn.rows) *reinterpret_cast<uint4*>(&lds[buf][f][c * 16]) = regs[f][m];     // row r, chunk k sits at (r cpr + k) 16 = c 16
+      }
+  };
+  prefetch(item);
+  commit(0);
+  __syncthreads();
+  int cur = 0;
+  for (;;) {
+    const TileHdr h = hn; const int off = offn, idx = idxn;
+    const unsigned tile = item % ntiles, fg = item / ntiles;
+    const unsigned next = item + nb;
+    if (next < hi) prefetch(next);
+    // ---- gather item `item` from lds[cur] (or from global memory: tiles whose box is too large) ----
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int orow = ty * TH + t / TW, ocol = tx * TW + t % TW;
+    const bool active = t < TW * TH && ocol < out_w && orow < out_h;
+    const size_t g = static_cast<size_t>(orow) * out_w + ocol;
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) {
+      const int frame = static_cast<int>(fg) * FPB + f;
+      if (frame >= batch) break;
+      uint32_t v;
+      if (h.staged) {
+        const uint8_t* l = &lds[cur][f][active ? off : 0];
+        v = uint32_t(l[0]) | (uint32_t(l[1]) << 8) | (uint32_t(l[2]) << 16);
+      } else {
+        const uint8_t* sa = src + static_cast<size_t>(frame) * src_stride + (active ? static_cast<size_t>(idx) * 3 : 0);
+        v = uint32_t(sa[0]) | (uint32_t(sa[1]) << 8) | (uint32_t(sa[2]) << 16);
+      }
+      const uint32_t nx = __builtin_amdgcn_update_dpp(0u, v, 0xF9, 0xf, 0xf, false);
+      const uint32_t d = (v >> (8 * j)) | (nx << (24 - 8 * j));
+      if (active && j < 3) reinterpret_cast<uint32_t*>(out + static_cast<size_t>(frame) * out_stride + (g & ~size_t(3)) * 3)[j] = d;
+    }
+    if (next >= hi) break;
+    commit(cur ^ 1);
+    __syncthreads();
+    item = next; cur ^= 1;
+  }
+}
+
+// variant 16: as 10 but BIG tiles: TW x TH = 256 PPT pixels per block, PPT per lane (lane t owns tile pixels t, t + 256, ...):
+// one latency for PPT times the pixels, and a larger tile wastes less of its box.
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void gather_tiled_big(const TileHdr* __restrict__ hdr, const unsigned short* __restrict__ t16,
+                                                        const int* __restrict__ t32, int tiles_x, int out_w, int out_h,
+                                                        const uint8_t* __restrict__ src, size_t src_stride, int src_pitch,
+                                                        uint8_t* __restrict__ out, size_t out_stride, int batch, int fpb,
+                                                        int lds_per_frame) {
+  constexpr int PPT = TW * TH / 256;
+  static_assert(TW * TH % 256 == 0 && TW % 4 == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tile = blockIdx.x, t = threadIdx.x, j = t & 3;
+  const TileHdr h = hdr[tile];
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int f0 = blockIdx.y * fpb, f1 = min(batch, f0 + fpb);
+  size_t g[PPT]; bool active[PPT];
+#pragma unroll
+  for (int m = 0; m < PPT; ++m) {
+    const int q = t + 256 * m, orow = ty * TH + q / TW, ocol = tx * TW + q % TW;
+    active[m] = ocol < out_w && orow < out_h;
+    g[m] = static_cast<size_t>(orow) * out_w + ocol;
+  }
+  auto store = [&](uint8_t* base, uint32_t v, int m) {
+    const uint32_t nx = __builtin_amdgcn_update_dpp(0u, v, 0xF9, 0xf, 0xf, false);
+    const uint32_t d = (v >> (8 * j)) | (nx << (24 - 8 * j));
+    if (active[m] && j < 3) reinterpret_cast<uint32_t*>(base + (g[m] & ~size_t(3)) * 3)[j] = d;
+  };
+  if (!h.staged) {
+    for (int f = f0; f < f1; ++f) {
+      const uint8_t* sa = src + static_cast<size_t>(f) * src_stride;
+      uint32_t v[PPT];
+#pragma unroll
+      for (int m = 0; m < PPT; ++m) {
+        const size_t p = active[m] ? static_cast<size_t>(t32[static_cast<size_t>(tile) * (TW * TH) + t + 256 * m]) * 3 : 0;
+        v[m] = uint32_t(sa[p]) | (uint32_t(sa[p + 1]) << 8) | (uint32_t(sa[p + 2]) << 16);
+      }
+#pragma unroll
+      for (int m = 0; m < PPT; ++m) store(out + static_cast<size_t>(f) * out_stride, v[m], m);
+    }
+    return;
+  }
+  const int cpr = h.rowbytes >> 4, chunks = cpr * h.rows;
+  const float inv = 1.0f / static_cast<float>(cpr);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* sa = src + static_cast<size_t>(f) * src_stride + h.base;
+    uint8_t* l = lds + (f - f0) * lds_per_frame;
+    for (int c = t; c < chunks; c += 256) {
+      const int r = static_cast<int>((static_cast<float>(c) + 0.5f) * inv), k = c - r * cpr;
+      *reinterpret_cast<uint4*>(l + c * 16) = *reinterpret_cast<const uint4*>(sa + static_cast<size_t>(r) * src_pitch + k * 16);
+    }
+  }
+  __syncthreads();
+  int off[PPT];
+#pragma unroll
+  for (int m = 0; m < PPT; ++m) off[m] = active[m] ? t16[static_cast<size_t>(tile) * (TW * TH) + t + 256 * m] : 0;
+  for (int f = f0; f < f1; ++f)
+#pragma unroll
+    for (int m = 0; m < PPT; ++m) {
+      const uint8_t* l = lds + (f - f0) * lds_per_frame + off[m];
+      store(out + static_cast<size_t>(f) * out_stride, uint32_t(l[0]) | (uint32_t(l[1]) << 8) | (uint32_t(l[2]) << 16), m);
+    }
+}
+
+template <int TW, int TH>
+int run_tiled_big(const std::vector<int>& ht, int S, int H, int W, int F, int iters, const uint8_t* src, size_t srcb, uint8_t* out,
+                  const uint8_t* ref, size_t outb, int budget) {
+  constexpr int NPX = TW * TH;
+  const int out_w = 6 * S, tiles_x = (out_w + TW - 1) / TW, tiles_y = (S + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+  std::vector<TileHdr> hh(ntiles);
+  std::vector<unsigned short> h16(size_t(ntiles) * NPX);
+  std::vector<int> h32(size_t(ntiles) * NPX);
+  size_t staged = 0, lds_max = 0; double box_bytes = 0;
+  for (int ty = 0; ty < tiles_y; ++ty)
+    for (int tx = 0; tx < tiles_x; ++tx) {
+      const int tile = ty * tiles_x + tx;
+      int rmin = H, rmax = -1, cmin = W, cmax = -1;
+      for (int q = 0; q < NPX; ++q) {
+        const int orow = ty * TH + q / TW, ocol = tx * TW + q % TW;
+        if (orow >= S || ocol >= out_w) { h32[size_t(tile) * NPX + q] = -1; continue; }
+        const int idx = ht[size_t(orow) * out_w + ocol];
+        h32[size_t(tile) * NPX + q] = idx;
+        rmin = std::min(rmin, idx / W); rmax = std::max(rmax, idx / W); cmin = std::min(cmin, idx % W); cmax = std::max(cmax, idx % W);
+      }
+      const long long rowstart = static_cast<long long>(rmin) * W * 3, b0 = (rowstart + cmin * 3) & ~15ll;
+      const int rowbytes = static_cast<int>((((rowstart + cmax * 3 + 3) - b0) + 15) & ~15ll), rows = rmax - rmin + 1;
+      TileHdr h{static_cast<unsigned>(b0), static_cast<unsigned short>(rows), static_cast<unsigned short>(rowbytes), 0, 0};
+      const long long end = b0 + static_cast<long long>(rows - 1) * W * 3 + rowbytes;
+      if (static_cast<long long>(rows) * rowbytes <= budget && end <= static_cast<long long>(srcb)) {
+        h.staged = 1; ++staged; lds_max = std::max<size_t>(lds_max, size_t(rows) * rowbytes); box_bytes += double(rows) * rowbytes;
+        for (int q = 0; q < NPX; ++q) {
+          const int idx = h32[size_t(tile) * NPX + q];
+          if (idx >= 0) h16[size_t(tile) * NPX + q] = static_cast<unsigned short>((idx / W - rmin) * rowbytes + (rowstart + (idx % W) * 3 - b0));
+        }
+      }
+      hh[tile] = h;
+    }
+  TileHdr* dh; unsigned short* d16; int* d32;
+  CK(hipMalloc(&dh, hh.size() * sizeof(TileHdr))); CK(hipMalloc(&d16, h16.size() * 2)); CK(hipMalloc(&d32, h32.size() * 4));
+  CK(hipMemcpy(dh, hh.data(), hh.size() * sizeof(TileHdr), hipMemcpyHostToDevice));
+  CK(hipMemcpy(d16, h16.data(), h16.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(d32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
+  const int lds_per_frame = static_cast<int>((lds_max + 15) & ~size_t(15));
+  std::printf("BIG tile %3dx%2d budget %5d: %zu of %d tiles staged, largest box %zu B, mean box %.0f B (%d B of pixels)\n", TW, TH, budget, staged,
+              ntiles, lds_max, box_bytes / std::max<size_t>(staged, 1), NPX * 3);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int fpb : {1, 2}) {
+    if (size_t(lds_per_frame) * fpb > 65536) continue;
+    const unsigned gy = (F + fpb - 1) / fpb;
+    auto launch = [&]() {
+      hipLaunchKernelGGL((gather_tiled_big<TW, TH>), dim3(ntiles, gy), dim3(256), size_t(lds_per_frame) * fpb, 0, dh, d16, d32, tiles_x, out_w, S, src,
+                         srcb, W * 3, out, outb, F, fpb, lds_per_frame);
+    };
+    CK(hipMemset(out, 0, outb * F));
+    launch(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int it = 0; it < iters; ++it) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    std::vector<uint8_t> a(outb), b(outb);
+    CK(hipMemcpy(a.data(), out + outb * (F - 1), outb, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), ref + outb * (F - 1), outb, hipMemcpyDeviceToHost));
+    std::printf("  fpb %d big %dx%d: %.3f ms / %d frames = %.2f us per frame, %.0f GB/s algorithmic, %s\n", fpb, TW, TH, ms, F, ms * 1e3 / F,
+                double(F) * S * 6 * S * 6 / (ms * 1e-3) / 1e9, std::memcmp(a.data(), b.data(), outb) == 0 ? "same" : "DIFFERENT");
+  }
+  CK(hipFree(dh)); CK(hipFree(d16)); CK(hipFree(d32));
+  return 0;
+}
+
 template <int TW, int TH>
 int run_tiled(const std::vector<int>& ht, int S, int H, int W, int F, int iters, const uint8_t* src, size_t srcb, uint8_t* out,
               const uint8_t* ref, size_t outb, int budget) {
@@ -366,6 +581,32 @@ int run_tiled(const std::vector<int>& ht, int S, int H, int W, int F, int iters,
     CK(hipMemcpy(a.data(), out + outb * (F - 1), outb, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), ref + outb * (F - 1), outb, hipMemcpyDeviceToHost));
     std::printf("  fpb %d tiled %dx%d: %.3f ms / %d frames = %.0f frames/s, %.0f GB/s algorithmic, %s\n", fpb, TW, TH, ms, F, F / (ms * 1e-3),
                 double(F) * S * 6 * S * 6 / (ms * 1e-3) / 1e9, std::memcmp(a.data(), b.data(), outb) == 0 ? "same" : "DIFFERENT");
+  }
+  if (budget == 8192) {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    for (int bpc : {2, 3, 4}) {
+      constexpr int FPB = 2;
+      const unsigned groups = (F + FPB - 1) / FPB, total = groups * ntiles;
+      const unsigned grid = static_cast<unsigned>(prop.multiProcessorCount) * bpc / 8 * 8;
+      auto launch = [&]() {
+        hipLaunchKernelGGL((gather_tiled_persistent<TW, TH, FPB, 8192>), dim3(grid), dim3(256), 0, 0, dh, d16, d32, ntiles, tiles_x, out_w, S,
+                           src, srcb, W * 3, out, outb, F, total);
+      };
+      CK(hipMemset(out, 0, outb * F));
+      launch(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      for (int it = 0; it < iters; ++it) launch();
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+      std::vector<uint8_t> a(outb), b(outb);
+      bool same = true;
+      for (int fr : {0, F / 2, F - 1}) {
+        CK(hipMemcpy(a.data(), out + outb * fr, outb, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), ref + outb * fr, outb, hipMemcpyDeviceToHost));
+        same = same && std::memcmp(a.data(), b.data(), outb) == 0;
+      }
+      std::printf("  persistent %dx%d, %d blocks/CU: %.3f ms / %d frames = %.2f us per frame, %.0f GB/s algorithmic, %s\n", TW, TH, bpc, ms, F,
+                  ms * 1e3 / F, double(F) * S * 6 * S * 6 / (ms * 1e-3) / 1e9, same ? "same" : "DIFFERENT");
+    }
   }
   CK(hipFree(dh)); CK(hipFree(d16)); CK(hipFree(d32));
   return 0;
@@ -456,12 +697,16 @@ int main(int argc, char** argv) {
       }
       CK(hipMemset(out, 0, outb * F));
     }
+    for (int budget : {12288, 16384, 24576, 32768}) {
+      if (run_tiled_big<64, 16>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled_big<32, 16>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled_big<64, 8>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled_big<32, 32>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+      if (run_tiled_big<128, 8>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+    }
     for (int budget : {8192}) {
       if (run_tiled<32, 8>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
-      if (run_tiled<24, 10>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
-      if (run_tiled<40, 6>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
-      if (run_tiled<60, 4>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
-      if (run_tiled<20, 12>(ht, S, H, W, F, iters, src, srcb, out, ref, outb, budget)) return 1;
+
     }
     return 0;
   }

@@ -88,6 +88,10 @@ if a.frames > 0:
     out["equi2cube"] = {"frames": F, "ms_per_batch": ms, "frames_per_s": F / (ms * 1e-3),
                         "algorithmic_GBps": F * S * 6 * S * 6 / (ms * 1e-3) / 1e9,
                         "host_decided_table_entries": int(lib.sba_map_table_host_decided(0, 0, S, H, W))}
-    out["algorithmic_bytes_per_launch"]["gather_kernel<true>"] = F * S * 6 * S * 6
-    out["units_per_launch"]["gather_kernel<true>"] = F * S * 6 * S
+    for kname in ("gather_tiled_kernel<true>", "gather_kernel<true>"):      # whichever of the two the remap runs
+        out["algorithmic_bytes_per_launch"][kname] = F * S * 6 * S * 6
+        out["units_per_launch"][kname] = F * S * 6 * S
+    tiles, staged, lds = C.c_int(0), C.c_int(0), C.c_int(0)
+    lib.sba_map_table_tiles(0, 0, S, H, W, C.byref(tiles), C.byref(staged), C.byref(lds))
+    out["equi2cube"].update(tiles=tiles.value, staged_tiles=staged.value, lds_bytes_per_frame=lds.value)
 print(json.dumps(out))
