@@ -153,7 +153,9 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
   SBA_TRY_HIP(hipSetDevice(p->device));
   const size_t nvec = (p->n + 1) / 2;
   // 256-thread blocks (4 waves x 64 vectors of 2 matches), two resident per CU
-  const int grid = static_cast<int>(std::min<size_t>((nvec + 255) / 256, static_cast<size_t>(p->num_cus) * 2));
+  int per_cu = 2;
+  if (const char* e = std::getenv("SBA_EPI_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) per_cu = v; }   // tuning only
+  const int grid = static_cast<int>(std::min<size_t>((nvec + 255) / 256, static_cast<size_t>(p->num_cus) * per_cu));
   const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
   // scratch (block partials + the groups) lives in the handle: allocating 23 MB per call cost more than the pass
   const size_t need = (static_cast<size_t>(std::max(grid, 1)) + 1) * gsz;
