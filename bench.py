@@ -412,7 +412,8 @@ def main():
     seed = synthetic.BASE_SEED + (2 if rt else 1)
     c = gen(a.n, seed=seed, shard=rank)
 
-    # hook transport needs the problem on torch's current stream; native/none use the shim's own stream
+    # an explicitly requested hook transport runs on torch's current stream (no stream switch per collective);
+    # everything else -- including the hook that `auto` falls back to -- on the shim's own stream
     use_hook = world > 1 and a.transport == "hook"
     stream = torch.cuda.current_stream().cuda_stream if use_hook else None
     p = api.Problem(device_index, stream=stream)

@@ -8,8 +8,9 @@ Transports for that exchange (``attach(..., transport=...)``):
                 all ranks), then publishes to the host.  No collective library on the data path.
   * "rccl"   -- the C++ shim calls ``ncclAllReduce`` (RCCL) itself on the problem's stream; the 128-byte unique id is
                 shipped between ranks with ``torch.distributed``.
-  * "hook"   -- ``torch.distributed.all_reduce`` on a tensor aliasing the shim's device pack (needs the problem to
-                launch on torch's current stream).
+  * "hook"   -- ``torch.distributed.all_reduce`` on a tensor aliasing the shim's device pack, issued with the problem's
+                stream made torch's current stream (so it is ordered against the shim's kernels whichever stream the
+                problem was created on).
   * "auto"   -- "rccl" (the collective BASELINE's north star names) if every rank can load RCCL and joins the
                 communicator, else "hook".  "peer" is opt-in (``transport="peer"`` / ``SBA_TRANSPORT=peer``): its stores
                 into another DEVICE's IPC-mapped inbox have so far only run between processes on one GPU, so it is not
@@ -115,8 +116,7 @@ def _try_rccl(problem: api.Problem, torch, dist) -> bool:
 def attach(problem: api.Problem, transport: str = "auto", force: bool = False, prefer_native: bool | None = None) -> str:
     """Install the per-sweep exchange on `problem` for the current torch.distributed world.
     Returns the transport used: "none" (world size 1, unless `force`), "xgmi-peer", "rccl-native" or "torch-hook".
-    `transport`: "auto" (rccl, else hook) | "peer" | "rccl" | "hook" (env SBA_TRANSPORT overrides "auto").  The hook
-    transport requires the problem to have been created on torch's current stream."""
+    `transport`: "auto" (rccl, else hook) | "peer" | "rccl" | "hook" (env SBA_TRANSPORT overrides "auto")."""
     import torch
     import torch.distributed as dist
 
@@ -144,7 +144,9 @@ def _install_hook(problem: api.Problem, torch, dist) -> str:
     pack = torch.as_tensor(_DevicePack(pack_ptr, 24), device=dev)
     aliases = {(pack_ptr, 24): pack}
 
-    def hook(ptr, count, _stream):
+    streams = {}
+
+    def hook(ptr, count, stream):
         # the 24-double pack on every sweep; other device buffers (the 64 x 45 group moments of the initial guess)
         # get their own alias the first time they appear
         t = aliases.get((ptr, count))
@@ -153,7 +155,17 @@ def _install_hook(problem: api.Problem, torch, dist) -> str:
             if len(aliases) > 64:          # scratch buffers come and go: keep the table small
                 for k in [k for k in aliases if k != (pack_ptr, 24) and k != (ptr, count)]:
                     del aliases[k]
-        dist.all_reduce(t)
+        # The collective must be ordered after the kernels the shim has just enqueued on ITS stream and before the
+        # ones that follow: torch orders a collective against the current stream, so make the shim's stream current
+        # (a problem created on torch's own current stream needs nothing).
+        if stream and stream != torch.cuda.current_stream(dev).cuda_stream:
+            ext = streams.get(stream)
+            if ext is None:
+                ext = streams[stream] = torch.cuda.ExternalStream(stream, device=dev)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t)
+        else:
+            dist.all_reduce(t)
         return 0
     problem.set_allreduce(hook)
     problem.set_shard(dist.get_rank(), dist.get_world_size())

@@ -280,6 +280,14 @@ def test_distributed_attach_one_rank_process_group(oracle):
             assert (sd_hook.num_iterations, sd_hook.termination) == (sd_plain.num_iterations, sd_plain.termination)
             assert np.abs(d_hook - d_plain).max() <= 1e-12
             assert np.array_equal(p.epipolar_moments(), gm_plain)                # the hook aliases that buffer too
+        # the hook on a problem with its OWN stream (what "auto" falls back to when RCCL cannot be set up): the
+        # collective is issued with that stream current
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, c.d12)
+            assert distributed.attach(p, transport="hook", force=True) == "torch-hook"
+            assert np.array_equal(p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH), base)
+            r3, t3, s3 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            assert np.abs(r3 - r).max() <= 1e-12 and s3.num_iterations == s_.num_iterations
     finally:
         dist.destroy_process_group()
 
