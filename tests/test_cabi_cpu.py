@@ -86,3 +86,47 @@ def test_product_never_references_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", str(pkg / "libsba_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_null_and_nonsense_arguments_are_errors_not_crashes():
+    """Every entry point that takes pointers or sizes answers bad ones with a negative status and a message -- before it
+    touches a device (there is none here), and without dereferencing anything."""
+    import ctypes as C
+    lib = cabi.load_library()
+    null = C.c_void_p(None)
+    calls = {
+        "problem_create(null out)": lambda: lib.sba_problem_create(None, 0, null),
+        "problem_destroy(null)": lambda: lib.sba_problem_destroy(None),          # a no-op, not an error
+        "problem_upload(null handle)": lambda: lib.sba_problem_upload(None, None, None, None, 0, 0),
+        "problem_eval(null handle)": lambda: lib.sba_problem_eval(None, 0, 0, None, None, 1.0, 1.0, 1.0, None),
+        "problem_solve(null handle)": lambda: lib.sba_problem_solve(None, 0, 0, None, None, 1.0, 1.0, None, None),
+        "problem_comm_init_rank(null)": lambda: lib.sba_problem_comm_init_rank(None, 1, 0, None),
+        "problem_peer_export(null)": lambda: lib.sba_problem_peer_export(None, 2, 0, None),
+        "problem_peer_connect(null)": lambda: lib.sba_problem_peer_connect(None, None),
+        "batch_create(null out)": lambda: lib.sba_batch_create(None, 0, null),
+        "batch_eval(null handle)": lambda: lib.sba_batch_eval(None, 0, 0, None, None, None, None, 1.0, None),
+        "batch_solve(null handle)": lambda: lib.sba_batch_solve(None, 0, 0, None, None, None, None, None, None, None),
+        "batch_step_is_fused(null)": lambda: lib.sba_batch_step_is_fused(None),
+        "comm_unique_id(null)": lambda: lib.sba_comm_unique_id(None),
+        "equi2cube(null image)": lambda: lib.sba_equi2cube(0, None, 64, 128, 16, None),
+        "equi2cube_device(null image)": lambda: lib.sba_equi2cube_device(0, null, null, 64, 128, 16, 1, null),
+        "equi2cube_device(zero cube)": lambda: lib.sba_equi2cube_device(0, null, C.c_void_p(16), 64, 128, 0, 1, C.c_void_p(16)),
+        "equi2cube_device(zero batch)": lambda: lib.sba_equi2cube_device(0, null, C.c_void_p(16), 64, 128, 16, 0, C.c_void_p(16)),
+        "crop_rotated_image_device(null)": lambda: lib.sba_crop_rotated_image_device(0, null, null, 64, 128, C.c_float(0.0), 1, null),
+        "crop_rotated_image_device(tiny)": lambda: lib.sba_crop_rotated_image_device(0, null, C.c_void_p(16), 2, 128, C.c_float(0.0), 1, C.c_void_p(16)),
+        "keypoints_to_sphere(null)": lambda: lib.sba_keypoints_to_sphere(0, None, 5, 28, 128, 64, None),
+        "rotate_keypoints(null)": lambda: lib.sba_rotate_keypoints(0, None, 5, 28, C.c_float(45.0), 128, 64),
+        "rotate_keypoints(short stride)": lambda: lib.sba_rotate_keypoints(0, C.c_void_p(16), 5, 4, C.c_float(45.0), 128, 64),
+        "cube2equi_keypoints(null)": lambda: lib.sba_cube2equi_keypoints(0, None, 5, 28, 16, 128, 64),
+    }
+    for name, call in calls.items():
+        rc = call()
+        if name.startswith("problem_destroy"):
+            assert rc == cabi.SBA_OK, name
+            continue
+        assert rc < 0, (name, rc)
+        msg = lib.sba_last_error()
+        assert msg and len(msg) > 3, name
+    # diagnostics on a table that was never built: "not built", not an error code from a device call
+    assert lib.sba_map_table_host_decided(0, 0, 16, 64, 128) == -1
+    assert lib.sba_map_table_tiles(0, 0, 16, 64, 128, None, None, None) == -1
