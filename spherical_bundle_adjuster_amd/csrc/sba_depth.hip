@@ -61,15 +61,13 @@ __device__ __forceinline__ void store_pair_stream(double* plane, size_t pair, do
 // the candidate, one reciprocal) then run under the next step's loads instead of after them.
 template <typename ST>
 struct DepthRegs {
-  double X[2], Y[2], Z[2], U[2], V[2], W[2], A[2], B[2], S1[2], S2[2], DG1[2], DG2[2];
+  double X[2], Y[2], Z[2], U[2], V[2], W[2], A[2], B[2], S1[2], S2[2];
   __device__ __forceinline__ void load(const Planes& pl, const double* d1, const double* d2, const double* sc1,
-                                       const double* sc2, const double* dg1, const double* dg2, bool load_scale,
-                                       bool load_diag, size_t pr) {
+                                       const double* sc2, bool load_scale, size_t pr) {
     Pair<ST>::load(pl.x1[0], pr, X); Pair<ST>::load(pl.x1[1], pr, Y); Pair<ST>::load(pl.x1[2], pr, Z);
     Pair<ST>::load(pl.x2[0], pr, U); Pair<ST>::load(pl.x2[1], pr, V); Pair<ST>::load(pl.x2[2], pr, W);
     Pair<double>::load(d1, pr, A); Pair<double>::load(d2, pr, B);
     if (load_scale) { Pair<double>::load(sc1, pr, S1); Pair<double>::load(sc2, pr, S2); }
-    if (load_diag) { Pair<double>::load(dg1, pr, DG1); Pair<double>::load(dg2, pr, DG2); }
   }
 };
 
@@ -78,19 +76,18 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
                                                         const double* __restrict__ d2,
                                                         double* __restrict__ c1, double* __restrict__ c2,
                                                         double* __restrict__ sc1, double* __restrict__ sc2,
-                                                        double* __restrict__ dg1, double* __restrict__ dg2,
                                                         DepthParams P, double* __restrict__ partials) {
   __shared__ double red[4][DEPTH_OUT_COUNT];
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
-  const bool load_scale = !P.first_iteration, load_diag = P.reuse_diagonal != 0;
+  const bool load_scale = !P.first_iteration;
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gdelta = 0, cand_gdelta = 0, gmax = 0, dmax = 0;
   size_t pr = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   DepthRegs<ST> cur, nxt;
-  if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, dg1, dg2, load_scale, load_diag, pr);
+  if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, load_scale, pr);
   while (pr < npairs) {
     const size_t pn = pr + stride;
-    if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, dg1, dg2, load_scale, load_diag, pn);
+    if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, pn);
     double NA[2], NB[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -118,14 +115,11 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
         s1 = cur.S1[h]; s2 = cur.S2[h];
       }
       const double H11 = s1 * h11 * s1, H12 = s1 * h12 * s2, H22 = s2 * h22 * s2, G1 = s1 * g1, G2 = s2 * g2;
-      double D1, D2;
-      if (P.reuse_diagonal) {
-        D1 = cur.DG1[h]; D2 = cur.DG2[h];
-      } else {
-        D1 = fmin(fmax(H11, P.min_diagonal), P.max_diagonal);
-        D2 = fmin(fmax(H22, P.min_diagonal), P.max_diagonal);
-        cur.DG1[h] = D1; cur.DG2[h] = D2;
-      }
+      // The LM diagonal.  Ceres keeps the squared column norms of the last accepted point across rejected steps and
+      // line-search trials (reuse_diagonal_) -- but those passes run at that very point, so recomputing them here gives
+      // the same bits and the two planes that used to carry them (16 B per match and pass) are gone.
+      const double D1 = fmin(fmax(H11, P.min_diagonal), P.max_diagonal);
+      const double D2 = fmin(fmax(H22, P.min_diagonal), P.max_diagonal);
       // damped 2x2 system (H + D / radius) y = -G; 1 / radius comes from the host, 1 / det is formed once
       const double A11 = __builtin_fma(D1, P.inv_radius, H11), A22 = __builtin_fma(D2, P.inv_radius, H22), A12 = H12;
       const double inv_det = 1.0 / (A11 * A22 - A12 * A12);
@@ -155,7 +149,6 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
     }
     store_pair_stream(c1, pr, NA[0], NA[1]); store_pair_stream(c2, pr, NB[0], NB[1]);
     if (P.first_iteration) { store_pair_f64(sc1, pr, cur.S1[0], cur.S1[1]); store_pair_f64(sc2, pr, cur.S2[0], cur.S2[1]); }
-    if (!P.reuse_diagonal) { store_pair_f64(dg1, pr, cur.DG1[0], cur.DG1[1]); store_pair_f64(dg2, pr, cur.DG2[0], cur.DG2[1]); }
     cur = nxt;
     pr = pn;
   }
@@ -232,16 +225,16 @@ hipError_t depth_blocks_per_cu(int store, int* blocks) {
 }
 
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
-                             double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
+                             double* c2, double* sc1, double* sc2,
                              const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream) {
   if (grid > 0) {
     if (store == 0)
       hipLaunchKernelGGL((depth_step_kernel<double>), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1,
-                         sc2, dg1, dg2, prm, partials);
+                         sc2, prm, partials);
     else
       hipLaunchKernelGGL((depth_step_kernel<float>), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1,
-                         sc2, dg1, dg2, prm, partials);
+                         sc2, prm, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

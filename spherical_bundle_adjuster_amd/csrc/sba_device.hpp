@@ -176,7 +176,8 @@ struct DepthParams {
   double min_diagonal, max_diagonal;
   double alpha;          // line-search step size: the candidate is P(d + alpha * delta); 1.0 for the trust-region step
   int first_iteration;   // compute and store the Jacobi scaling
-  int reuse_diagonal;    // previous step was rejected (or a line-search pass): keep the stored LM diagonal
+  int reuse_diagonal;    // previous step was rejected (or a line-search pass): Ceres keeps its LM diagonal -- the pass
+                         // recomputes it at the same point (identical bits), nothing is stored
   int jacobi_scaling;
   int pad_;
   unsigned long long n;
@@ -184,10 +185,10 @@ struct DepthParams {
 // Results of one pass: the DEPTH_OUT_* slots of out / host_out (sba_depth_solver.hpp): seven sums and two maxima.
 // gather_slot >= 0 (sharded problem): `out` is a 24-double pack for a SUM all-reduce, the sums in [0..6], this rank's
 // two maxima in [8 + gather_slot] and [16 + gather_slot] (gather_slot < 8), zeros elsewhere; nothing is published to
-// the host.  Candidates go to (c1, c2); (sc*, dg*) hold the per-parameter scaling / diagonal.  partials: [grid][16].
+// the host.  Candidates go to (c1, c2); (sc*) hold the per-parameter Jacobi scaling.  partials: [grid][16].
 hipError_t depth_blocks_per_cu(int store, int* blocks);   // resident 256-thread blocks per CU of depth_step_kernel
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
-                             double* c2, double* sc1, double* sc2, double* dg1, double* dg2,
+                             double* c2, double* sc1, double* sc2,
                              const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream);
 

@@ -43,11 +43,10 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   // the kernel writes whole pairs only, and a candidate plane becomes the problem's depth plane when a step is accepted
   // -- its padding must be zeros like the uploaded planes' (a later per-match sweep loads it in its ragged tail).
   sba::DeviceBuffer work_buf, partials_buf, out_buf;
-  SBA_TRY_HIP(work_buf.alloc(6 * elems * sizeof(double)));
-  SBA_TRY_HIP(hipMemsetAsync(work_buf.ptr, 0, 6 * elems * sizeof(double), p->stream));
+  SBA_TRY_HIP(work_buf.alloc(4 * elems * sizeof(double)));
+  SBA_TRY_HIP(hipMemsetAsync(work_buf.ptr, 0, 4 * elems * sizeof(double), p->stream));
   double* work = work_buf.as<double>();
-  double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems, *dg1 = work + 4 * elems,
-         *dg2 = work + 5 * elems;
+  double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems;
   // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
   int& occ = p->depth_occ[p->store];
   if (occ == 0) {
@@ -83,7 +82,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     prm.radius = rq.radius; prm.inv_radius = 1.0 / rq.radius; prm.alpha = rq.alpha;
     prm.first_iteration = rq.first ? 1 : 0; prm.reuse_diagonal = rq.keep_diagonal ? 1 : 0;
     if (collective) {
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
                                          p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
       int rc = allreduce_pack(p);
       if (rc) return rc;
@@ -101,13 +100,13 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     if (p->publish) {
       // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
       const unsigned long long seq = ++p->seq;
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
                                          out_dev, p->pack_host_dev, seq, -1, p->stream));
       const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), seq,
                                             p->stream, "d-only pass");
       if (rc) return rc;
     } else {
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, dg1, dg2, prm, partials, grid,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
                                          out_dev, nullptr, 0, -1, p->stream));
       SBA_TRY_HIP(hipMemcpyAsync(p->pack_host, out_dev, sizeof(out), hipMemcpyDeviceToHost, p->stream));
       SBA_TRY_HIP(hipStreamSynchronize(p->stream));
