@@ -10,6 +10,8 @@ correspondences with per-match depths (64 algorithmic bytes per evaluation: 2 x 
 components + 2 f64 depths), f64 arithmetic.  At N > 1: one GPU's shard of BASELINE config C4 ("100M
 correspondences sharded 8xMI355X") = 12.5M of the same correspondences per GPU, one RCCL all-reduce of the
 24-double pack per step (the collective north_star names; `--transport peer` selects the direct xGMI exchange).
+At N = 1 the line also carries `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
+child run of `--workload c5` after the timed region (`--no-c5-leg` skips it).
 At N > 1 the line also carries `peer_trial`: after the quoted measurement, the same K steps once more over the direct
 peer exchange -- a second figure, never the quoted `value` (`--no-peer-trial` skips it).
 A *step* is one pass of the hot path over the resident correspondences exactly as one LM iteration needs it: sweep
@@ -72,6 +74,8 @@ def parse():
                          "the shim: what north_star names) and, only if RCCL cannot be set up on every rank, the "
                          "torch.distributed hook; rccl = RCCL or fail; peer = direct xGMI exchange (opt-in)")
     ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
+    ap.add_argument("--no-c5-leg", action="store_true",
+                    help="N = 1: skip the config-C5 figures (`c5` in the line: a child run of --workload c5)")
     ap.add_argument("--no-peer-trial", action="store_true",
                     help="N > 1: skip the second, un-quoted measurement over the direct xGMI peer exchange")
     return ap.parse_args()
@@ -312,6 +316,29 @@ def pmc_traffic_named(kernel_prefix: str, units: int):
     return None
 
 
+def c5_leg(steps: int, warmup: int):
+    """N = 1, after the timed region: BASELINE config C5 (256 ERP pairs x 50k matches: batched step, per-pair LM, 512-frame
+    remap) measured by a child run of `bench.py --workload c5` with the same K / W, condensed.  A secondary figure in the
+    same driver-run line; it cannot disturb the headline (own process, bounded time, errors reported as text)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "c5", "--steps", str(steps), "--warmup", str(warmup),
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=240, cwd=str(ROOT))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"ok": False, "error": (r.stderr or r.stdout)[-300:]}
+        d = json.loads(lines[-1])
+        rf = d["roofline"]
+        return {"ok": True, "workload": d["config"]["workload"], "evals_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                "steps": d["steps"], "warmup": d["warmup"], "step": d["config"]["step"],
+                "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                    "sweep_kernel_alone")},
+                "lm": d["lm"], "equi2cube": d["equi2cube"],
+                "what": "child run of `python bench.py --workload c5` (same K / W) after the timed region"}
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
+
 def peer_trial(p, transport, dist, torch, run_steps, barrier, ref_pack, world, n):
     """N > 1, after the quoted measurement: the same K steps over the direct xGMI peer exchange (tools: DESIGN.md 5).
     Never the quoted `value`; it exists so that the first multi-GPU run also says what one-launch peer stores cost
@@ -529,6 +556,10 @@ def main():
                             "kernel's access pattern and no residual/Jacobian arithmetic"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c, mode, rt, a.cpu_sample, a.cpu_seconds)
+    if rank == 0:
+        if world == 1 and not rehearsal and not a.no_c5_leg and rt and a.store == "f64":
+            p.close()                       # the child gets the GPU to itself
+            out["c5"] = c5_leg(a.steps, a.warmup)
         print(json.dumps(out), flush=True)
     p.close()
     if dist is not None:

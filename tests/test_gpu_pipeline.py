@@ -106,3 +106,29 @@ def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
     assert np.abs(got_tran - t2).max() < 2e-5 * max(1, np.abs(t2).max())
     # and the guess itself is in the neighbourhood of the true rotation
     assert np.abs(rot0 - c.rot_true).max() < 0.2
+
+
+def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
+    """`python bench.py` as the driver runs it at N = 1 (smaller problem, same code path): ONE JSON line with the contract's
+    keys, `roofline` and `cpu_baseline`, and the config-C5 figures from the child run (`c5`)."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--matches", "300000", "--steps", "5", "--warmup", "2",
+                        "--cpu-seconds", "1", "--cpu-sample", "100000", "--precondition-ms", "5"],
+                       capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in b, key
+    assert b["n_gpus"] == 1 and b["steps"] == 5 and b["dtype"] == "f64" and b["vs_baseline"] is None
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(b["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(b["cpu_baseline"]) and b["cpu_baseline"]["kind"] == "port"
+    c5 = b["c5"]
+    assert c5["ok"], c5
+    assert c5["roofline"]["kernel"].startswith("batch_step_kernel") and 0.3 < c5["roofline"]["frac"] < 1.0
+    assert c5["lm"]["all_converged"] and c5["equi2cube"]["frames"] == 512
