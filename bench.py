@@ -11,7 +11,8 @@ components + 2 f64 depths), f64 arithmetic.  At N > 1: one GPU's shard of BASELI
 correspondences sharded 8xMI355X") = 12.5M of the same correspondences per GPU, one RCCL all-reduce of the
 24-double pack per step (the collective north_star names; `--transport peer` selects the direct xGMI exchange).
 At N = 1 the line also carries `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
-child run of `--workload c5` after the timed region (`--no-c5-leg` skips it).
+child run of `--workload c5` after the timed region (`--no-c5-leg` skips it), and `stages`: the 8-point initial guess and the
+bounded d-only stage of `solve_problem` on the resident problem (`--no-stage-leg`).
 At N > 1 the line also carries `peer_trial`: after the quoted measurement, the same K steps once more over the direct
 peer exchange -- a second figure, never the quoted `value` (`--no-peer-trial` skips it).
 A *step* is one pass of the hot path over the resident correspondences exactly as one LM iteration needs it: sweep
@@ -74,6 +75,8 @@ def parse():
                          "the shim: what north_star names) and, only if RCCL cannot be set up on every rank, the "
                          "torch.distributed hook; rccl = RCCL or fail; peer = direct xGMI exchange (opt-in)")
     ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
+    ap.add_argument("--no-stage-leg", action="store_true",
+                    help="N = 1: skip the initial-guess / d-only-stage figures (`stages` in the line)")
     ap.add_argument("--no-c5-leg", action="store_true",
                     help="N = 1: skip the config-C5 figures (`c5` in the line: a child run of --workload c5)")
     ap.add_argument("--no-peer-trial", action="store_true",
@@ -314,6 +317,31 @@ def pmc_traffic_named(kernel_prefix: str, units: int):
     except Exception:
         pass
     return None
+
+
+def stage_leg(p, c, n: int):
+    """N = 1, after the timed region, on the resident problem: the stages either side of the sweep in `solve_problem` --
+    8-point moments + initial guess and the bounded d-only stage (f-2), wall clock, host-synchronous."""
+    import numpy as np
+    try:
+        out = {"ok": True, "matches": n}
+        p.epipolar_moments()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            p.epipolar_moments()
+        out["epipolar_moments_ms_incl_fold_and_d2h"] = (time.perf_counter() - t0) / 10 * 1e3
+        out["epipolar_algorithmic_bytes"] = n * 48
+        t0 = time.perf_counter(); p.initial_guess(80, 0.25, 0); out["initial_guess_ms_80_trials"] = (time.perf_counter() - t0) * 1e3
+        d0 = np.full((n, 2), 5.0)
+        p.set_depths(d0); p.solve_depths(c.rot_true, c.tran_true)          # first call: scratch allocations
+        p.set_depths(d0)
+        _, s = p.solve_depths(c.rot_true, c.tran_true)
+        out["depth_stage"] = {"iterations": s.num_iterations, "passes": s.num_evaluations, "line_search_steps": s.num_line_search_steps,
+                              "ms_total": s.seconds_total * 1e3, "us_per_pass": s.seconds_total / max(s.num_evaluations, 1) * 1e6,
+                              "algorithmic_bytes_per_pass": n * 96, "termination": s.termination}
+        return out
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
 
 def c5_leg(steps: int, warmup: int):
@@ -557,6 +585,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c, mode, rt, a.cpu_sample, a.cpu_seconds)
     if rank == 0:
+        if world == 1 and not rehearsal and not a.no_stage_leg and rt:
+            out["stages"] = stage_leg(p, c, a.n)
         if world == 1 and not rehearsal and not a.no_c5_leg and rt and a.store == "f64":
             p.close()                       # the child gets the GPU to itself
             out["c5"] = c5_leg(a.steps, a.warmup)

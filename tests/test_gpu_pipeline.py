@@ -132,3 +132,5 @@ def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
     assert c5["ok"], c5
     assert c5["roofline"]["kernel"].startswith("batch_step_kernel") and 0.3 < c5["roofline"]["frac"] < 1.0
     assert c5["lm"]["all_converged"] and c5["equi2cube"]["frames"] == 512
+    st = b["stages"]
+    assert st["ok"] and st["depth_stage"]["termination"].startswith("CONVERGENCE") and st["initial_guess_ms_80_trials"] > 0

@@ -43,7 +43,7 @@ with api.Problem(0) as p:
                           "termination": s.termination}
 out["algorithmic_bytes_per_launch"]["epipolar_moments_kernel<double>"] = n * 48
 out["units_per_launch"]["epipolar_moments_kernel<double>"] = n
-# steady-state pass of the d-only stage: 48 B coordinates + 16 B depths + 16 B scaling + 16 B diagonal + 16 B candidates
+# steady-state pass of the d-only stage: 48 B coordinates + 16 B depths + 16 B scaling + 16 B candidates
 out["algorithmic_bytes_per_launch"]["depth_step_kernel<double>"] = n * 96
 out["units_per_launch"]["depth_step_kernel<double>"] = n
 del c
