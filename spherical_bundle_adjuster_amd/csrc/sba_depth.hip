@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void depth_step_kernel(Planes pl, const double
         NA[h] = 0.0; NB[h] = 0.0;   // keep the padding zero
       }
     }
-    store_pair_stream(c1, pr, NA[0], NA[1]); store_pair_stream(c2, pr, NB[0], NB[1]);
+    if (P.stream_stores) { store_pair_stream(c1, pr, NA[0], NA[1]); store_pair_stream(c2, pr, NB[0], NB[1]); }
+    else { store_pair_f64(c1, pr, NA[0], NA[1]); store_pair_f64(c2, pr, NB[0], NB[1]); }
     if (P.first_iteration) { store_pair_f64(sc1, pr, cur.S1[0], cur.S1[1]); store_pair_f64(sc2, pr, cur.S2[0], cur.S2[1]); }
     cur = nxt;
     pr = pn;

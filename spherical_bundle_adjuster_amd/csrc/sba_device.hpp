@@ -179,7 +179,7 @@ struct DepthParams {
   int reuse_diagonal;    // previous step was rejected (or a line-search pass): Ceres keeps its LM diagonal -- the pass
                          // recomputes it at the same point (identical bits), nothing is stored
   int jacobi_scaling;
-  int pad_;
+  int stream_stores;     // candidate planes stored non-temporally (1) or with plain stores (0)
   unsigned long long n;
 };
 // Results of one pass: the DEPTH_OUT_* slots of out / host_out (sba_depth_solver.hpp): seven sums and two maxima.

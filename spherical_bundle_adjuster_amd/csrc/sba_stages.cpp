@@ -70,7 +70,9 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   for (int i = 0; i < 3; ++i) prm.t[i] = tran[i];
   prm.lambda = lambda; prm.c = c;
   prm.min_diagonal = o.min_lm_diagonal; prm.max_diagonal = o.max_lm_diagonal;
-  prm.jacobi_scaling = o.jacobi_scaling; prm.pad_ = 0; prm.n = n;
+  prm.jacobi_scaling = o.jacobi_scaling; prm.n = n;
+  prm.stream_stores = 1;
+  if (const char* env = std::getenv("SBA_DEPTH_NT_STORES")) prm.stream_stores = std::atoi(env) != 0 ? 1 : 0;   // A/B (profiles/r03_depth_stores.md)
 
   double* cur1 = p->dplane[0];
   double* cur2 = p->dplane[1];

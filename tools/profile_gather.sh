@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): PMC passes over tools/gather_workload.py -- what bounds gather_kernel?
+# Run ON THE GPU BOX (through gpurun): PMC passes over tools/gather_workload.py -- what bounds the remap's gather kernel (gather_tiled_kernel by default)?
 # (A pass with TA_BUSY_avr / TA_*_STALLED_* / TCP_PENDING_STALL_CYCLES aborted inside rocprofv3 on this pool and then sat
 # silent until gpurun killed it: those counters are left out.)  Every pass prints a line so a slow one is not taken for hung.
 set -o pipefail
@@ -22,8 +22,8 @@ import csv, glob, collections
 for f in sorted(glob.glob("$OUT/p*/*counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "gather_kernel" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        print(f.split("/")[-2], k, "launches", len(v), "mean %.6g" % (sum(v) / len(v)))
+        if "gather" in r["Kernel_Name"]:      # gather_tiled_kernel (default) or gather_kernel
+            acc[(r["Kernel_Name"].split("(")[0][:32], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (kn, k), v in acc.items():
+        print(f.split("/")[-2], kn, k, "launches", len(v), "mean %.6g" % (sum(v) / len(v)))
 PY

@@ -90,13 +90,16 @@ __global__ __launch_bounds__(kBlock) void probe_kernel(PlanePtrs pl, size_t nvec
 }
 
 // Mixed read / write stream (the d-only stage's pattern): NR planes read once (nt loads), NW planes written once (nt
-// stores), 16 B per lane, grid-stride, next step's loads in flight while the current step is stored.
-struct MixedPtrs { const double2* r[12]; double2* w[4]; };
-template <int NR, int NW>
+// stores with NTS, plain stores otherwise), 16 B per lane, grid-stride, next step's loads in flight while the current
+// step is stored.  Every load is consumed: the sums also go into one store per wave at the end (without it the
+// read-only variants are dead code and "run" in 4 us).
+struct MixedPtrs { const double2* r[12]; double2* w[4]; double* sink; };
+template <int NR, int NW, bool NTS>
 __global__ __launch_bounds__(kBlock) void mixed_kernel(MixedPtrs pl, size_t nvec) {
   const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
   size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   double2 cur[NR], nxt[NR];
+  double acc = 0.0;
   if (p < nvec)
 #pragma unroll
     for (int k = 0; k < NR; ++k) cur[k] = ld<true>(pl.r[k] + p);
@@ -108,16 +111,20 @@ __global__ __launch_bounds__(kBlock) void mixed_kernel(MixedPtrs pl, size_t nvec
     double sx = 0.0, sy = 0.0;
 #pragma unroll
     for (int k = 0; k < NR; ++k) { sx += cur[k].x; sy += cur[k].y; }
+    acc += sx * sy;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
       typedef float f4 __attribute__((ext_vector_type(4)));
       const double2 q = make_double2(sx + k, sy - k);
-      __builtin_nontemporal_store(*reinterpret_cast<const f4*>(&q), reinterpret_cast<f4*>(pl.w[k] + p));
+      if (NTS) __builtin_nontemporal_store(*reinterpret_cast<const f4*>(&q), reinterpret_cast<f4*>(pl.w[k] + p));
+      else pl.w[k][p] = q;
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) cur[k] = nxt[k];
     p = pn;
   }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) pl.sink[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = acc;
 }
 
 typedef void (*Kern)(PlanePtrs, size_t, double*, unsigned long long*);
@@ -150,11 +157,14 @@ int main(int argc, char** argv) {
     }
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    CHECK(hipMalloc(reinterpret_cast<void**>(&mp.sink), static_cast<size_t>(cus) * 16 * 4 * sizeof(double)));
     struct { const char* name; void (*k)(MixedPtrs, size_t); int nr, nw; } mv[] = {
-        {"10 read + 2 written (pass with the diagonal reused)", mixed_kernel<10, 2>, 10, 2},
-        {" 8 read + 4 written (pass that stores a new diagonal)", mixed_kernel<8, 4>, 8, 4},
-        {"12 read + 0 written", mixed_kernel<12, 0>, 12, 0},
-        {" 8 read + 0 written (the sweep's planes)", mixed_kernel<8, 0>, 8, 0}};
+        {"10 read + 2 written nt  (the d-only pass)", mixed_kernel<10, 2, true>, 10, 2},
+        {"10 read + 2 written plain", mixed_kernel<10, 2, false>, 10, 2},
+        {" 8 read + 4 written nt  (pass that also stores the scaling)", mixed_kernel<8, 4, true>, 8, 4},
+        {" 8 read + 4 written plain", mixed_kernel<8, 4, false>, 8, 4},
+        {"12 read + 0 written", mixed_kernel<12, 0, true>, 12, 0},
+        {" 8 read + 0 written (the sweep's planes)", mixed_kernel<8, 0, true>, 8, 0}};
     for (auto& v : mv)
       for (int bpc : {1, 2, 4}) {
         const int grid = cus * bpc;
@@ -170,6 +180,7 @@ int main(int argc, char** argv) {
         std::printf("mixed %-55s %d blocks/CU  %7.1f us  %6.0f GB/s (read + written)\n", v.name, bpc, us, bytes / us * 1e-3);
       }
     for (int k = 0; k < 16; ++k) CHECK(hipFree(mb[k]));
+    CHECK(hipFree(mp.sink));
     return 0;
   }
   PlanePtrs pl;
