@@ -188,6 +188,11 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     return lib
 
 
+def last_error(lib: C.CDLL) -> str:
+    msg = lib.sba_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
 def check(lib: C.CDLL, rc: int) -> None:
     if rc != SBA_OK:
         msg = lib.sba_last_error()

@@ -100,9 +100,15 @@ class Problem:
 
     # -- life cycle ---------------------------------------------------------------------------
     def close(self) -> None:
+        """Destroy the handle.  `destroy_status` keeps the library's answer: non-zero means the handle was POISONED (a
+        device wait timed out or the device faulted) and its device resources were leaked instead of freed -- the
+        process should then exit non-zero; never raise from here, close() runs inside `with` blocks that are unwinding."""
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.sba_problem_destroy(self._h)
+            self.destroy_status = int(self._lib.sba_problem_destroy(self._h))
             self._h = C.c_void_p()
+            if self.destroy_status != 0:
+                import warnings
+                warnings.warn("sba_problem_destroy: " + cabi.last_error(self._lib), ResourceWarning, stacklevel=2)
 
     def __enter__(self):
         return self
@@ -320,9 +326,13 @@ class Batch:
         self.num_pairs = 0
 
     def close(self) -> None:
+        """As Problem.close(): `destroy_status` != 0 = the batch was poisoned and its device resources were leaked."""
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.sba_batch_destroy(self._h)
+            self.destroy_status = int(self._lib.sba_batch_destroy(self._h))
             self._h = C.c_void_p()
+            if self.destroy_status != 0:
+                import warnings
+                warnings.warn("sba_batch_destroy: " + cabi.last_error(self._lib), ResourceWarning, stacklevel=2)
 
     def __enter__(self):
         return self

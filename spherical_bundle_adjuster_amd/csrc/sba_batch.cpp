@@ -21,6 +21,8 @@ struct sba_batch {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  int poisoned = 0;            // a device wait timed out or the device faulted (sba_internal.hpp): the handle is refused
+                               // from then on -- its ticket word and sequence numbers are out of step -- destroy leaks
   int num_cus = 0;
   int kind = SBA_KERNEL_FACTORED;
 
@@ -78,6 +80,7 @@ int free_batch_data(sba_batch* b) {
 
 int check_batch_args(const sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran) {
   if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  SBA_REFUSE_POISONED(b);
   if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
   if (mode < SBA_MODE_ROT || mode > SBA_MODE_RT) return sba::set_error(SBA_ERR_INVALID_ARG, "bad mode %d", mode);
   if (depth_mode != SBA_DEPTH_UNIFORM && depth_mode != SBA_DEPTH_PER_MATCH)
@@ -123,14 +126,14 @@ int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, cons
     SBA_TRY_HIP(sba::launch_batch_step_fused(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
                                              b->desc_dev, B, b->packs_dev, b->packs_host_dev, b->lm_ticket, seq, b->stream));
     return sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B), seq, b->stream,
-                                  "batched step");
+                                  "batched step", &b->poisoned);
   }
   if (!b->publish) {
     SBA_TRY_HIP(sba::launch_batch_step(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
                                        b->params_dev, b->frames_dev, b->desc_dev, B, b->bpp, b->partials, b->packs_dev,
                                        nullptr, 0, b->stream));
     SBA_TRY_HIP(hipMemcpyAsync(b->packs_host, b->packs_dev, sizeof(double) * 24 * B, hipMemcpyDeviceToHost, b->stream));
-    SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+    { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
     return SBA_OK;
   }
   const unsigned long long seq = ++b->seq;
@@ -138,7 +141,7 @@ int batch_launch(sba_batch* b, int mode, int depth_mode, const double* rot, cons
                                      b->params_dev, b->frames_dev, b->desc_dev, B, b->bpp, b->partials, b->packs_dev,
                                      b->packs_host_dev, seq, b->stream));
   return sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B), seq, b->stream,
-                                "batched sweep");
+                                "batched sweep", &b->poisoned);
 }
 
 // The packs arrive in the SBA_PACK_* layout (the finalize kernel converts the factored kernel's moments on the device).
@@ -237,7 +240,14 @@ int sba_batch_create(sba_batch** out, int device, void* stream) {
 int sba_batch_destroy(sba_batch* b) {
   if (!b) return SBA_OK;
   (void)hipSetDevice(b->device);
-  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  // Bounded drain; a poisoned handle keeps its device resources (hipFree / hipHostFree / hipStreamDestroy wait for the
+  // wedged device -- gpurun_out/r2_gputest10.log shows a close() blocked here for good).
+  if (!b->poisoned && b->stream) (void)sba::stream_wait(b->stream, "destroy", &b->poisoned);
+  if (b->poisoned) {
+    delete b;
+    return sba::set_error(SBA_ERR_HIP, "batch destroyed while poisoned: its device memory and stream were leaked (a device "
+                                       "wait timed out or the device faulted); the process should exit non-zero");
+  }
   free_batch_data(b);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
@@ -254,6 +264,7 @@ int sba_batch_set_kernel(sba_batch* b, int kind) {
 int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_xyz, const double* d12,
                      const size_t* offsets, int num_pairs, int store) {
   if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  SBA_REFUSE_POISONED(b);
   if (num_pairs < 0 || (num_pairs > 0 && !offsets)) return sba::set_error(SBA_ERR_INVALID_ARG, "bad offsets / num_pairs");
   if (store != SBA_STORE_F64 && store != SBA_STORE_F32) return sba::set_error(SBA_ERR_INVALID_ARG, "bad store %d", store);
   for (int g = 0; g < num_pairs; ++g)
@@ -332,7 +343,7 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   // stage the AoS arrays whole, then re-lay each pair out at its plane offset
   const size_t base = offsets[0];
   if (total > 0) {
-    sba::DeviceBuffer stage_buf;
+    sba::DeviceBuffer stage_buf(&b->poisoned);
     SBA_TRY_HIP(stage_buf.alloc(total * 3 * sizeof(double)));
     double* stage = stage_buf.as<double>();
     const double* src[2] = {left_xyz, right_xyz};
@@ -342,17 +353,17 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
         SBA_TRY_HIP(sba::launch_aos_to_planes(stage + 3 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
                                               b->coord[3 * side], b->coord[3 * side + 1], b->coord[3 * side + 2],
                                               store, b->stream));
-      SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+      { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
     }
     if (d12) {
       SBA_TRY_HIP(hipMemcpyAsync(stage, d12 + 2 * base, total * 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
       for (int g = 0; g < num_pairs; ++g)
         SBA_TRY_HIP(sba::launch_d12_to_planes(stage + 2 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
                                               b->dplane[0], b->dplane[1], b->stream));
-      SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+      { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
     }
   }
-  SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+  { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
   b->uploaded = true;
   return SBA_OK;
 }
@@ -504,12 +515,12 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
       const unsigned long long seq = ++b->seq;
       SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B,
                                        b->lm_ticket, flag_dev, seq, b->stream));
-      const int wrc = sba::wait_for_sequence(flag, seq, b->stream, "batched per-pair solve");
+      const int wrc = sba::wait_for_sequence(flag, seq, b->stream, "batched per-pair solve", &b->poisoned);
       if (wrc) return wrc;
     } else {
       SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B,
                                        b->lm_ticket, nullptr, 0, b->stream));
-      SBA_TRY_HIP(hipStreamSynchronize(b->stream));
+      { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
     }
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     int failures = 0;

@@ -338,19 +338,23 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
 #else
 #define SBA_TICK(acc) do { } while (0)
 #endif
-  // ONE thread-0 region per iteration, directly in front of the loop's first barrier: it consumes the previous sweep's
-  // sums (if any), then publishes either "done" or the next sweep state.  (Two thread-0 regions either side of the
-  // back edge -- feed at the bottom, prepare at the top -- invite the compiler to thread them into a private inner loop
-  // for the other 255 threads, whose barrier then runs without lane 0: tests/test_isa_checks_cpu.py guards the shape.)
-  // evals_left bounds the loop independently of the solver (which needs at most max_num_iterations + 1 evaluations).
-  bool have_sums = false;
-  int evals_left = opt.max_num_iterations + 8;
-  for (;;) {
+  // The loop is block-uniform BY CONSTRUCTION, not by what one compiler happens to emit:
+  //   * the trip count is bounded by a counter every thread keeps (`trip`), not by state only thread 0 sees;
+  //   * the ONE thread-0 region of a trip sits between two barriers of that same trip (B0 ... B1) -- there is no
+  //     thread-0-only code between the sweep's last barrier and the back edge, nor between the back edge and B0, so no
+  //     divergent region is adjacent to the back edge for a jump-threading pass to splice into a private inner loop
+  //     (that is what once left the other 255 threads at a barrier without lane 0: the kernel never finished);
+  //   * every thread takes the exit decision from the LDS word `done_s`, read after B1.
+  // tests/test_isa_checks_cpu.py remains as the second line: all four barriers at loop depth 1 in every instantiation,
+  // with the Makefile's flags and with the profiling variants.  The solver needs at most max_num_iterations + 1 sweeps.
+  const int max_trips = opt.max_num_iterations + 8;
+  for (int trip = 0; trip < max_trips; ++trip) {
+    __syncthreads();                        // B0: the previous trip's sums (raw_s) are complete
     if (tid == 0) {
 #ifdef SBA_LM_PROFILE
-      tk0 = wall_clock64();
+      if (trip > 0) SBA_TICK(tk_sweep); else tk0 = wall_clock64();   // profiling ticks live in THIS region too: none at the back edge
 #endif
-      if (have_sums) {
+      if (trip > 0) {
         double pack[24];
         if (KIND == KIND_FACTORED && MODE != MODE_TRAN)
           moments_to_normal_pack(true, MODE == MODE_RT, frame_s, frame_s + 9, raw_s, pack);
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
         solver->feed(ne);
         SBA_TICK(tk_feed);
       }
-      done_s = (solver->done() || evals_left-- <= 0) ? 1 : 0;
+      done_s = solver->done() ? 1 : 0;
       if (!done_s) {
         fill_sweep_params(n, DEPTH, solver->query_rot(), solver->query_tran(), depth_s[0], depth_s[1], opt.huber_delta, &prm_s,
                           KIND == KIND_EXPLICIT);
@@ -370,14 +374,10 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
       }
       SBA_TICK(tk_prep);
     }
-    __syncthreads();
+    __syncthreads();                        // B1: done_s / the next sweep state are visible to the block
     if (done_s) break;
     const SweepParams prm = prm_s;        // LDS broadcast -> registers, held across the sweep
-    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, first, n, prm, wave_out, raw_s);
-    have_sums = true;
-#ifdef SBA_LM_PROFILE
-    if (tid == 0) SBA_TICK(tk_sweep);
-#endif
+    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, first, n, prm, wave_out, raw_s);   // two barriers, the last one at its end
   }
   if (tid == 0) {
     BatchLmIo res;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     res.summary.initial_cost = static_cast<double>(tk_prep); res.summary.final_cost = static_cast<double>(tk_sweep);
     res.summary.final_gradient_max_norm = static_cast<double>(tk_conv); res.summary.final_radius = static_cast<double>(tk_feed);
 #endif
-    res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // evals_left ran out: cannot happen, but never silent
+    res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // max_trips ran out: cannot happen, but never silent
     res.pad_ = 0;
     io[pair] = res;
     // Completion: this block's record is in host memory (system-scope release + vmcnt(0)) before it takes a ticket; the

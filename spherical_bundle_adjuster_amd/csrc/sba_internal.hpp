@@ -14,8 +14,24 @@ int host_threads();
 // Host side of the publish protocol: a kernel stores its results into mapped pinned host memory, fences at system
 // scope, then stores `seq` into `*flag`; the host polls that word.  A stream query every 4096 spins turns a device
 // fault into an error instead of an endless spin.  `what` names the work in the error text.
+// `poisoned` (may be null) is the owning handle's poison word: it is set to 1 when the wait gives up (SBA_WAIT_TIMEOUT_S)
+// or the stream reports a device error -- the work enqueued on that stream can then never be waited for again.
 int wait_for_sequence(const volatile unsigned long long* flag, unsigned long long seq, hipStream_t stream,
-                      const char* what);
+                      const char* what, int* poisoned = nullptr);
+// Bounded replacement of hipStreamSynchronize for a handle's stream: polls hipStreamQuery, gives up after
+// SBA_WAIT_TIMEOUT_S like wait_for_sequence and poisons the handle then (or on a device error).
+int stream_wait(hipStream_t stream, const char* what, int* poisoned);
+
+// A handle whose device work timed out or faulted is POISONED: every later entry point on it fails with SBA_ERR_HIP, and
+// its destroy must not touch the wedged stream again -- hipStreamSynchronize / hipFree / hipHostFree / hipStreamDestroy
+// all wait for the device and would block for ever.  Destroy then leaks the device resources, frees the host object and
+// returns SBA_ERR_HIP; the process is expected to exit (non-zero), never to re-exec.
+#define SBA_REFUSE_POISONED(h)                                                                                        \
+  do {                                                                                                                \
+    if ((h)->poisoned)                                                                                                \
+      return sba::set_error(SBA_ERR_HIP, "handle is poisoned: an earlier device wait timed out or the device faulted; " \
+                                         "destroy it (its device memory is leaked) and exit the process");              \
+  } while (0)
 
 // Host-side per-sweep state from (rot, tran, depths, delta): SweepParams for the device, and the frame
 // (B, J) that maps the factored kernel's moments to normal equations.
@@ -23,12 +39,16 @@ void make_sweep_params(size_t n, int depth_mode, const double rot[3], const doub
                        double huber_delta, SweepParams* prm);
 
 // Scratch device memory that is released on every exit path.
+// `poison` (may be null): the owning handle's poison word -- hipFree waits for the device, so a buffer whose handle got
+// poisoned meanwhile is leaked instead of freed.
 struct DeviceBuffer {
   void* ptr = nullptr;
+  const int* poison = nullptr;
   DeviceBuffer() = default;
+  explicit DeviceBuffer(const int* poison_word) : poison(poison_word) {}
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-  ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+  ~DeviceBuffer() { if (ptr && !(poison && *poison)) (void)hipFree(ptr); }
   hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes > 0 ? bytes : 1); }
   template <typename T> T* as() const { return static_cast<T*>(ptr); }
 };

@@ -17,13 +17,15 @@ struct sba_problem {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  int poisoned = 0;            // a device wait on `stream` timed out or the device faulted (sba_internal.hpp): every entry
+                               // point refuses the handle from then on, destroy leaks the device resources
   int num_cus = 0;
   int blocks_per_cu_cap = 0;   // SBA_BLOCKS_PER_CU: resident blocks per CU used; 0 = the per-variant default of grid_for
                                // (1 or 2: the register double buffer supplies the memory-level parallelism, more
                                // waves only add rows to fold and finish-time spread, profiles/r01_tune_caps.log)
   int kind = SBA_KERNEL_FACTORED;
   int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
-  int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
+  int depth_occ[2][3] = {{0, 0, 0}, {0, 0, 0}};   // same for depth_step_kernel per [store][register variant]
   double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
   size_t epi_scratch_elems = 0;
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep

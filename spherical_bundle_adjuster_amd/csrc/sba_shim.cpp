@@ -52,32 +52,70 @@ int fail(int code, const char* fmt, ...) {
 
 namespace sba {
 int host_threads() { return g_host_threads.load(); }
-int wait_for_sequence(const volatile unsigned long long* flag, unsigned long long seq, hipStream_t stream,
-                      const char* what) {
-  // Wall-clock bound (SBA_WAIT_TIMEOUT_S, default 60 s): a device that never publishes -- a wedged kernel keeps the
-  // stream at hipErrorNotReady for ever -- must come back as an error, not as a spinning host thread.
+namespace {
+double wait_limit_seconds() {
   static const double limit_s = [] {
     const char* env = std::getenv("SBA_WAIT_TIMEOUT_S");
     const double v = env ? std::atof(env) : 60.0;
     return v > 0.0 ? v : 60.0;
   }();
+  return limit_s;
+}
+}  // namespace
+int wait_for_sequence(const volatile unsigned long long* flag, unsigned long long seq, hipStream_t stream,
+                      const char* what, int* poisoned) {
+  // Wall-clock bound (SBA_WAIT_TIMEOUT_S, default 60 s): a device that never publishes -- a wedged kernel keeps the
+  // stream at hipErrorNotReady for ever -- must come back as an error, not as a spinning host thread.  Giving up (or a
+  // device error) poisons the handle: nothing may wait on that stream again, not even its destroy.
+  const double limit_s = wait_limit_seconds();
   std::chrono::steady_clock::time_point t0;
   bool timing = false;
   for (unsigned long spins = 0; *flag != seq; ++spins) {
     if ((spins & 0xfff) == 0xfff) {
       const hipError_t q = hipStreamQuery(stream);
-      if (q != hipSuccess && q != hipErrorNotReady)
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        if (poisoned) *poisoned = 1;
         return set_error(SBA_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
-      if (q == hipSuccess && *flag != seq) return set_error(SBA_ERR_HIP, "%s finished without publishing its result", what);
+      }
+      if (q == hipSuccess && *flag != seq) {
+        if (poisoned) *poisoned = 1;    // the protocol state (sequence numbers, tickets) can no longer be trusted
+        return set_error(SBA_ERR_HIP, "%s finished without publishing its result", what);
+      }
       const auto now = std::chrono::steady_clock::now();
       if (!timing) { t0 = now; timing = true; }
-      else if (std::chrono::duration<double>(now - t0).count() > limit_s)
+      else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
+        if (poisoned) *poisoned = 1;
         return set_error(SBA_ERR_HIP, "%s: no result from the device after %.0f s (SBA_WAIT_TIMEOUT_S)", what, limit_s);
+      }
     }
     __builtin_ia32_pause();
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return SBA_OK;
+}
+int stream_wait(hipStream_t stream, const char* what, int* poisoned) {
+  const double limit_s = wait_limit_seconds();
+  std::chrono::steady_clock::time_point t0;
+  bool timing = false;
+  for (unsigned long spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) return SBA_OK;
+    if (q != hipErrorNotReady) {
+      if (poisoned) *poisoned = 1;
+      return set_error(SBA_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
+    }
+    if (spins >= 256) {     // ~0.3 ms of polling, then yield the core between queries and watch the clock
+      const auto now = std::chrono::steady_clock::now();
+      if (!timing) { t0 = now; timing = true; }
+      else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
+        if (poisoned) *poisoned = 1;
+        return set_error(SBA_ERR_HIP, "%s: the stream did not drain within %.0f s (SBA_WAIT_TIMEOUT_S)", what, limit_s);
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(spins < 4096 ? 20 : 500));
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
 }
 int set_error(int code, const char* fmt, ...) {
   char buf[512];
@@ -108,6 +146,12 @@ using sba::shim::rccl;
     if (_e != hipSuccess)                                                                   \
       return fail(SBA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                   __LINE__);                                                                \
+  } while (0)
+
+#define SBA_SYNC(p, what)                                                   \
+  do {                                                                      \
+    const int _rc = sba::stream_wait((p)->stream, what, &(p)->poisoned);    \
+    if (_rc) return _rc;                                                    \
   } while (0)
 
 }  // namespace
@@ -183,6 +227,7 @@ int grid_for(sba_problem* p, int mode, int depth_mode, bool loss, int* grid) {
 
 int check_args(const sba_problem* p, int mode, int depth_mode, const double* rot, const double* tran) {
   if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  SBA_REFUSE_POISONED(p);
   if (!rot || !tran) return fail(SBA_ERR_INVALID_ARG, "rot/tran must not be null");
   if (mode < SBA_MODE_ROT || mode > SBA_MODE_RT) return fail(SBA_ERR_INVALID_ARG, "bad mode %d", mode);
   if (depth_mode != SBA_DEPTH_UNIFORM && depth_mode != SBA_DEPTH_PER_MATCH)
@@ -265,14 +310,14 @@ namespace shim {
 int fetch_pack_raw(sba_problem* p, double raw[SBA_PACK_SIZE]) {
   if (p->published) {
     const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), p->seq,
-                                          p->stream, "sweep");
+                                          p->stream, "sweep", &p->poisoned);
     if (rc) return rc;
     if (p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
       return fail(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's pack");
   } else {
     SBA_HIP_TRY(hipMemcpyAsync(p->pack_host, p->pack_dev, SBA_PACK_SIZE * sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
-    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    SBA_SYNC(p, "stream synchronisation");
   }
   std::memcpy(raw, p->pack_host, SBA_PACK_SIZE * sizeof(double));
   return SBA_OK;
@@ -396,7 +441,14 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
 int sba_problem_destroy(sba_problem* p) {
   if (!p) return SBA_OK;
   (void)hipSetDevice(p->device);
-  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  // Drain the stream with the bounded wait; a handle that is (or hereby becomes) poisoned keeps its device resources:
+  // hipFree / hipHostFree / hipStreamDestroy / ncclCommDestroy / hipIpcCloseMemHandle all wait for the wedged device.
+  if (!p->poisoned && p->stream) (void)sba::stream_wait(p->stream, "destroy", &p->poisoned);
+  if (p->poisoned) {
+    delete p;   // host object only; the mapped pinned pack stays allocated (a wedged kernel may still store into it)
+    return fail(SBA_ERR_HIP, "problem destroyed while poisoned: its device memory, stream and communicator were leaked "
+                             "(a device wait timed out or the device faulted); the process should exit non-zero");
+  }
   if (p->comm) {
     Rccl& r = rccl();
     if (r.ok) r.CommDestroy(p->comm);
@@ -419,6 +471,7 @@ int sba_problem_destroy(sba_problem* p) {
 static int upload_common(sba_problem* p, const void* left, const void* right, const void* d12,
                          size_t n, int store, bool from_device) {
   if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  SBA_REFUSE_POISONED(p);
   if (store != SBA_STORE_F64 && store != SBA_STORE_F32)
     return fail(SBA_ERR_INVALID_ARG, "bad store %d", store);
   if (n > 0 && (!left || !right)) return fail(SBA_ERR_INVALID_ARG, "null coordinate array");
@@ -438,7 +491,7 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
       // Bounded staging buffer: chunks of <= 4M correspondences (96 MB) go H2D then are re-laid
       // out as planes on the device.
       const size_t chunk = std::min<size_t>(n, size_t(4) << 20);
-      sba::DeviceBuffer stage_buf;
+      sba::DeviceBuffer stage_buf(&p->poisoned);
       SBA_HIP_TRY(stage_buf.alloc(chunk * 3 * sizeof(double)));
       double* stage = stage_buf.as<double>();
       const double* src[2] = {static_cast<const double*>(left), static_cast<const double*>(right)};
@@ -450,7 +503,7 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
           SBA_HIP_TRY(sba::launch_aos_to_planes(stage, m, first, p->coord[3 * side + 0],
                                                 p->coord[3 * side + 1], p->coord[3 * side + 2],
                                                 store, p->stream));
-          SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+          SBA_SYNC(p, "stream synchronisation");
         }
       if (d12)
         for (size_t first = 0; first < n; first += chunk) {
@@ -458,11 +511,11 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
           SBA_HIP_TRY(hipMemcpyAsync(stage, static_cast<const double*>(d12) + 2 * first,
                                      m * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
           SBA_HIP_TRY(sba::launch_d12_to_planes(stage, m, first, p->dplane[0], p->dplane[1], p->stream));
-          SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+          SBA_SYNC(p, "stream synchronisation");
         }
     }
   }
-  SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+  SBA_SYNC(p, "stream synchronisation");
   p->uploaded = true;
   return SBA_OK;
 }
@@ -475,6 +528,7 @@ int sba_problem_upload(sba_problem* p, const double* left_xyz, const double* rig
 int sba_problem_upload_keypoints(sba_problem* p, const void* left_keypoints, const void* right_keypoints, size_t n,
                                  size_t stride_bytes, int im_width, int im_height, const double* d12, int store) {
   if (!p) return fail(SBA_ERR_INVALID_ARG, "null problem handle");
+  SBA_REFUSE_POISONED(p);
   if (store != SBA_STORE_F64 && store != SBA_STORE_F32) return fail(SBA_ERR_INVALID_ARG, "bad store %d", store);
   if (n > 0 && (!left_keypoints || !right_keypoints)) return fail(SBA_ERR_INVALID_ARG, "null key-point array");
   if (stride_bytes < 8 || stride_bytes % 4 != 0) return fail(SBA_ERR_INVALID_ARG, "stride_bytes must be a multiple of 4 and >= 8");
@@ -483,14 +537,14 @@ int sba_problem_upload_keypoints(sba_problem* p, const void* left_keypoints, con
   int rc = alloc_planes(p, n, d12 != nullptr, store);
   if (rc) return rc;
   if (n > 0) {
-    sba::DeviceBuffer kl, kr;
+    sba::DeviceBuffer kl(&p->poisoned), kr(&p->poisoned);
     SBA_HIP_TRY(kl.alloc(n * stride_bytes));
     SBA_HIP_TRY(kr.alloc(n * stride_bytes));
     SBA_HIP_TRY(hipMemcpyAsync(kl.ptr, left_keypoints, n * stride_bytes, hipMemcpyHostToDevice, p->stream));
     SBA_HIP_TRY(hipMemcpyAsync(kr.ptr, right_keypoints, n * stride_bytes, hipMemcpyHostToDevice, p->stream));
     SBA_HIP_TRY(sba::launch_keypoints_to_planes(kl.as<uint8_t>(), kr.as<uint8_t>(), n, stride_bytes, im_width, im_height,
                                                 p->coord, store, p->stream));
-    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    SBA_SYNC(p, "stream synchronisation");
   }
   p->uploaded = true;
   if (d12) return sba_problem_set_depths(p, d12);
@@ -504,6 +558,7 @@ int sba_problem_upload_device(sba_problem* p, const void* left_xyz_dev, const vo
 
 int sba_problem_set_depths(sba_problem* p, const double* d12) {
   if (!p || !d12) return fail(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
   if (!p->uploaded) return fail(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   SBA_HIP_TRY(hipSetDevice(p->device));
   if (!p->has_d12) {
@@ -516,11 +571,11 @@ int sba_problem_set_depths(sba_problem* p, const double* d12) {
     p->has_d12 = true;
   }
   if (p->n > 0) {
-    sba::DeviceBuffer stage;
+    sba::DeviceBuffer stage(&p->poisoned);
     SBA_HIP_TRY(stage.alloc(p->n * 2 * sizeof(double)));
     SBA_HIP_TRY(hipMemcpyAsync(stage.ptr, d12, p->n * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
     SBA_HIP_TRY(sba::launch_d12_to_planes(stage.as<double>(), p->n, 0, p->dplane[0], p->dplane[1], p->stream));
-    SBA_HIP_TRY(hipStreamSynchronize(p->stream));
+    SBA_SYNC(p, "stream synchronisation");
   }
   return SBA_OK;
 }

@@ -22,6 +22,7 @@ extern "C" {
 int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double tran[3], double lambda,
                              double c, const sba_lm_options* opt, double* d12_out, sba_lm_summary* summary) {
   if (!p || !rot || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
   if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   if (!p->has_d12 && p->n > 0) return sba::set_error(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
   // Sharded problem: the nine global reductions of every pass are all-reduced over the attached transport (the two
@@ -42,15 +43,17 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, results.  Zeroed once:
   // the kernel writes whole pairs only, and a candidate plane becomes the problem's depth plane when a step is accepted
   // -- its padding must be zeros like the uploaded planes' (a later per-match sweep loads it in its ragged tail).
-  sba::DeviceBuffer work_buf, partials_buf, out_buf;
+  sba::DeviceBuffer work_buf(&p->poisoned), partials_buf(&p->poisoned), out_buf(&p->poisoned);   // leaked, not freed, if a pass poisons the handle
   SBA_TRY_HIP(work_buf.alloc(4 * elems * sizeof(double)));
   SBA_TRY_HIP(hipMemsetAsync(work_buf.ptr, 0, 4 * elems * sizeof(double), p->stream));
   double* work = work_buf.as<double>();
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems;
   // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
-  int& occ = p->depth_occ[p->store];
+  int variant = 2;      // register budget the kernel variant is compiled for, in resident blocks per CU
+  if (const char* env = std::getenv("SBA_DEPTH_OCC")) { const int v = std::atoi(env); if (v >= 2 && v <= 4) variant = v; }
+  int& occ = p->depth_occ[p->store][variant - 2];
   if (occ == 0) {
-    SBA_TRY_HIP(sba::depth_blocks_per_cu(p->store, &occ));
+    SBA_TRY_HIP(sba::depth_blocks_per_cu(p->store, variant, &occ));
     occ = std::max(1, occ);
   }
   int cap = 8;
@@ -71,8 +74,10 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   prm.lambda = lambda; prm.c = c;
   prm.min_diagonal = o.min_lm_diagonal; prm.max_diagonal = o.max_lm_diagonal;
   prm.jacobi_scaling = o.jacobi_scaling; prm.n = n;
-  prm.stream_stores = 1;
-  if (const char* env = std::getenv("SBA_DEPTH_NT_STORES")) prm.stream_stores = std::atoi(env) != 0 ? 1 : 0;   // A/B (profiles/r03_depth_stores.md)
+  // Plain stores for the candidate planes: 167.4 us per pass against 181.3 us with non-temporal stores (rocprofv3
+  // averages over 54 launches at 10^7 matches, same box; WRITE_SIZE is 160.8 MB either way -- profiles/r03_depth_stores.md).
+  prm.stream_stores = 0;
+  if (const char* env = std::getenv("SBA_DEPTH_NT_STORES")) prm.stream_stores = std::atoi(env) != 0 ? 1 : 0;
 
   double* cur1 = p->dplane[0];
   double* cur2 = p->dplane[1];
@@ -84,7 +89,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     prm.radius = rq.radius; prm.inv_radius = 1.0 / rq.radius; prm.alpha = rq.alpha;
     prm.first_iteration = rq.first ? 1 : 0; prm.reuse_diagonal = rq.keep_diagonal ? 1 : 0;
     if (collective) {
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid, variant,
                                          p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
       int rc = allreduce_pack(p);
       if (rc) return rc;
@@ -102,16 +107,16 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     if (p->publish) {
       // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
       const unsigned long long seq = ++p->seq;
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid, variant,
                                          out_dev, p->pack_host_dev, seq, -1, p->stream));
       const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), seq,
-                                            p->stream, "d-only pass");
+                                            p->stream, "d-only pass", &p->poisoned);
       if (rc) return rc;
     } else {
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid, variant,
                                          out_dev, nullptr, 0, -1, p->stream));
       SBA_TRY_HIP(hipMemcpyAsync(p->pack_host, out_dev, sizeof(out), hipMemcpyDeviceToHost, p->stream));
-      SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+      { const int _rc = sba::stream_wait(p->stream, "stream synchronisation", &p->poisoned); if (_rc) return _rc; }
     }
     std::memcpy(out, p->pack_host, sizeof(out));
     return SBA_OK;
@@ -136,13 +141,13 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     SBA_TRY_HIP(hipMemcpyAsync(p->dplane[1], cur2, elems * sizeof(double), hipMemcpyDeviceToDevice, p->stream));
   }
   if (d12_out && n > 0) {
-    sba::DeviceBuffer aos;
+    sba::DeviceBuffer aos(&p->poisoned);
     SBA_TRY_HIP(aos.alloc(2 * n * sizeof(double)));
     SBA_TRY_HIP(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos.as<double>(), p->stream));
     SBA_TRY_HIP(hipMemcpyAsync(d12_out, aos.ptr, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+    { const int _rc = sba::stream_wait(p->stream, "stream synchronisation", &p->poisoned); if (_rc) return _rc; }
   }
-  SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+  { const int _rc = sba::stream_wait(p->stream, "stream synchronisation", &p->poisoned); if (_rc) return _rc; }
   if (rc_final != SBA_OK) return sba::set_error(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
   return SBA_OK;
 }
@@ -150,6 +155,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
 // ---- 8-point initial guess (reference .cpp:47-181) -------------------------------------------------------
 int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
   if (!p || !groups) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
   if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
   SBA_TRY_HIP(hipSetDevice(p->device));
   const size_t nvec = (p->n + 1) / 2;
@@ -179,7 +185,7 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups) {
     if (rc) return rc;
   }
   SBA_TRY_HIP(hipMemcpyAsync(groups, groups_dev, gsz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  SBA_TRY_HIP(hipStreamSynchronize(p->stream));
+  { const int _rc = sba::stream_wait(p->stream, "stream synchronisation", &p->poisoned); if (_rc) return _rc; }
   if (collective && p->peer_ready && reinterpret_cast<volatile unsigned long long*>(p->pack_host)[25] != 0)
     return sba::set_error(SBA_ERR_COMM, "peer exchange timed out waiting for another rank's group moments");
   return SBA_OK;

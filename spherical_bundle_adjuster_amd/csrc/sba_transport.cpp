@@ -139,6 +139,7 @@ int sba_comm_unique_id(char id[SBA_COMM_ID_BYTES]) {
 
 int sba_problem_comm_init_rank(sba_problem* p, int nranks, int rank, const char id[SBA_COMM_ID_BYTES]) {
   if (!p || !id) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
   if (nranks < 1 || rank < 0 || rank >= nranks) return sba::set_error(SBA_ERR_INVALID_ARG, "bad rank %d/%d", rank, nranks);
   Rccl& r = rccl();
   if (!r.ok) return sba::set_error(SBA_ERR_COMM, "%s", r.why.c_str());
@@ -167,7 +168,8 @@ int sba_problem_comm_destroy(sba_problem* p) {
   if (!p) return SBA_OK;
   if (p->comm) {
     (void)hipSetDevice(p->device);
-    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (!p->poisoned && p->stream) (void)sba::stream_wait(p->stream, "communicator tear-down", &p->poisoned);
+    SBA_REFUSE_POISONED(p);     // ncclCommDestroy waits for the communicator's stream: leak it
     Rccl& r = rccl();
     if (r.ok) r.CommDestroy(p->comm);
     p->comm = nullptr;
@@ -178,6 +180,7 @@ int sba_problem_comm_destroy(sba_problem* p) {
 // ---- direct peer exchange ---------------------------------------------------------------------------------------
 int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SBA_PEER_HANDLE_BYTES]) {
   if (!p || !handle) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
   if (nranks < 1 || nranks > sba::kMaxPeers || rank < 0 || rank >= nranks)
     return sba::set_error(SBA_ERR_INVALID_ARG, "bad rank %d/%d (at most %d ranks)", rank, nranks, sba::kMaxPeers);
   static_assert(sizeof(hipIpcMemHandle_t) == SBA_PEER_HANDLE_BYTES, "IPC handle size");
@@ -218,6 +221,7 @@ int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SB
 
 int sba_problem_peer_connect(sba_problem* p, const char* handles) {
   if (!p || !handles) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
   if (!p->inbox) return sba::set_error(SBA_ERR_INVALID_ARG, "call sba_problem_peer_export first");
   SBA_TRY_HIP(hipSetDevice(p->device));
   for (int r = 0; r < p->peers.nranks; ++r) {
@@ -241,7 +245,11 @@ int sba_problem_peer_connect(sba_problem* p, const char* handles) {
 int sba_problem_peer_disable(sba_problem* p) {
   if (!p) return SBA_OK;
   (void)hipSetDevice(p->device);
-  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (!p->poisoned && p->stream) (void)sba::stream_wait(p->stream, "peer tear-down", &p->poisoned);
+  if (p->poisoned) {            // closing / freeing the inboxes would wait for the wedged device: leak them
+    p->peer_ready = false;
+    SBA_REFUSE_POISONED(p);
+  }
   for (auto& o : p->peer_opened) {
     if (o) (void)hipIpcCloseMemHandle(o);
     o = nullptr;
@@ -257,6 +265,7 @@ int sba_problem_peer_disable(sba_problem* p) {
 int sba_problem_peer_selftest(sba_problem* p, int rounds, int* ok) {
   if (!p || !ok) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
   *ok = 0;
+  SBA_REFUSE_POISONED(p);
   if (!p->peer_ready) return sba::set_error(SBA_ERR_INVALID_ARG, "peer exchange is not connected");
   SBA_TRY_HIP(hipSetDevice(p->device));
   const int n = p->peers.nranks;

@@ -1,0 +1,208 @@
+// TEST HARNESS (tests/ only): the C-ABI's handle logic against a MOCK device whose stream can be wedged.
+// Links the product's host translation units (sba_shim / sba_transport / sba_stages / sba_batch .cpp, compiled with g++
+// against tests/harness/fake_hip) with a fake runtime (device memory = host memory) and stub kernel launchers:
+//   healthy: a launch that would publish stores its sequence number at once, the stream reads "drained";
+//   wedged : launches do nothing, hipStreamQuery says hipErrorNotReady for ever, and any call that would WAIT for the
+//            device on the real runtime (hipStreamSynchronize, hipFree, hipHostFree, hipStreamDestroy, hipDeviceSynchronize,
+//            hipEventSynchronize, hipMemcpy) is counted as a violation -- on a real wedged GPU it never returns
+//            (gpurun_out/r2_gputest10.log: blocked inside sba_batch_destroy).
+// Checks: a wait that times out (SBA_WAIT_TIMEOUT_S=1) returns SBA_ERR_HIP, the handle is then refused by every entry
+// point at once, and destroy returns promptly, non-zero, without a single blocking call.  Exit code 0 = all held.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sba_hip.h"
+#include "../../spherical_bundle_adjuster_amd/csrc/sba_device.hpp"
+
+namespace {
+bool g_wedged = false;
+int g_violations = 0;
+std::string g_violation_names;
+void blocking_call(const char* name) {
+  if (g_wedged) { ++g_violations; g_violation_names += std::string(name) + " "; }
+}
+void publish(double* host_dev, size_t word, unsigned long long seq) {
+  if (!g_wedged && host_dev) reinterpret_cast<volatile unsigned long long*>(host_dev)[word] = seq;
+}
+}  // namespace
+
+// ---- fake runtime ---------------------------------------------------------------------------------------------------
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : (e == hipErrorNotReady ? "not ready" : "fake error"); }
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* c) { *c = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "mock"); p->multiProcessorCount = 4; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }
+hipError_t hipDeviceSynchronize() { blocking_call("hipDeviceSynchronize"); return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipFree(void* p) { blocking_call("hipFree"); std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+hipError_t hipHostFree(void* p) { blocking_call("hipHostFree"); std::free(p); return hipSuccess; }
+hipError_t hipMemset(void* p, int v, size_t n) { blocking_call("hipMemset"); std::memset(p, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { if (!g_wedged) std::memset(p, v, n); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { blocking_call("hipMemcpy"); std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (!g_wedged) std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(std::malloc(8)); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { blocking_call("hipStreamDestroy"); std::free(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { blocking_call("hipStreamSynchronize"); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return g_wedged ? hipErrorNotReady : hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(std::malloc(8)); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { blocking_call("hipEventSynchronize"); return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return hipSuccess; }
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorUnknown; }
+hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorUnknown; }
+hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+
+// ---- stub kernel launchers (the .hip files are not part of this build) ---------------------------------------------------
+namespace sba {
+int points_per_lane(int store) { return store == 0 ? 2 : 4; }
+hipError_t sweep_blocks_per_cu(int, int, int, int, bool, int* b) { *b = 2; return hipSuccess; }
+hipError_t batch_blocks_per_cu(int, int, int, int, bool, int* b) { *b = 2; return hipSuccess; }
+hipError_t depth_blocks_per_cu(int, int, int* b) { *b = 2; return hipSuccess; }
+hipError_t launch_sweep(int, int, int, int, const Planes&, const SweepParams&, const SweepOut& o, int, hipStream_t) {
+  publish(o.pack_host, 24, o.seq); return hipSuccess;
+}
+hipError_t launch_finalize(const double*, int, double*, double* host, unsigned long long seq, const PeerInboxes*, unsigned long long, hipStream_t) {
+  publish(host, 24, seq); return hipSuccess;
+}
+hipError_t launch_publish(const double*, double* host, unsigned long long seq, hipStream_t) { publish(host, 24, seq); return hipSuccess; }
+hipError_t launch_peer_exchange(const double*, const PeerInboxes&, unsigned long long, double*, double* host, unsigned long long seq, hipStream_t) {
+  publish(host, 24, seq); return hipSuccess;
+}
+hipError_t launch_batch_step_fused(int, int, int, int, double, const Planes&, const BatchState*, const PairDesc*, int np, double*,
+                                   double* host, unsigned int*, unsigned long long seq, hipStream_t) {
+  publish(host, static_cast<size_t>(24) * np, seq); return hipSuccess;
+}
+hipError_t launch_batch_lm(int, int, int, int, const Planes&, const PairDesc*, BatchLmIo* io, const sba_lm_options&, int np, unsigned int*,
+                           unsigned long long* seq_host, unsigned long long seq, hipStream_t) {
+  if (!g_wedged) { for (int g = 0; g < np; ++g) io[g].status = SBA_OK; if (seq_host) *reinterpret_cast<volatile unsigned long long*>(seq_host) = seq; }
+  return hipSuccess;
+}
+hipError_t launch_batch_sweep(int, int, int, int, bool, const Planes&, const SweepParams*, const PairDesc*, int np, int, double*, double*,
+                              double* host, unsigned long long seq, hipStream_t) {
+  publish(host, static_cast<size_t>(24) * np, seq); return hipSuccess;
+}
+hipError_t launch_batch_sweep_only(int, int, int, int, bool, const Planes&, const SweepParams*, const PairDesc*, int, int, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_step(int, int, int, int, double, const Planes&, const BatchState*, SweepParams*, double*, const PairDesc*, int np, int,
+                             double*, double*, double* host, unsigned long long seq, hipStream_t) {
+  publish(host, static_cast<size_t>(24) * np, seq); return hipSuccess;
+}
+hipError_t launch_aos_to_planes(const double*, size_t, size_t, void*, void*, void*, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_d12_to_planes(const double*, size_t, size_t, double*, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_planes_to_d12(const double*, const double*, size_t, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_depth_step(int, const Planes&, const double*, const double*, double*, double*, double*, double*, const DepthParams&, double*,
+                             int, int, double*, double* host, unsigned long long seq, int, hipStream_t) {
+  publish(host, 24, seq); return hipSuccess;
+}
+hipError_t launch_epipolar_moments(int, const Planes&, size_t, double*, int, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_keypoints_to_sphere(const uint8_t*, size_t, size_t, double, double, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_keypoints_to_planes(const uint8_t*, const uint8_t*, size_t, size_t, double, double, void* const*, int, hipStream_t) { return hipSuccess; }
+}  // namespace sba
+
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "wedge_harness: check failed: %s (line %d); last error: %s\n", #c, __LINE__, sba_last_error()); return 1; } } while (0)
+
+static double seconds_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int main() {
+  const size_t n = 100;
+  std::vector<double> x(3 * n, 0.5), d12(2 * n, 1.0), pack(24);
+  const double rot[3] = {0.1, 0.2, 0.3}, tran[3] = {0, 0, 1};
+
+  // ---- single problem: healthy sweep, then the device stops answering in the middle of the next one ----------------------------
+  {
+    sba_problem* p = nullptr;
+    REQUIRE(sba_problem_create(&p, 0, nullptr) == SBA_OK);
+    REQUIRE(sba_problem_upload(p, x.data(), x.data(), d12.data(), n, SBA_STORE_F64) == SBA_OK);
+    REQUIRE(sba_problem_eval_pack(p, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rot, tran, 1, 1, 1.0, pack.data()) == SBA_OK);
+    g_wedged = true;
+    auto t0 = std::chrono::steady_clock::now();
+    REQUIRE(sba_problem_eval_pack(p, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rot, tran, 1, 1, 1.0, pack.data()) == SBA_ERR_HIP);
+    REQUIRE(std::strstr(sba_last_error(), "SBA_WAIT_TIMEOUT_S") != nullptr);
+    REQUIRE(seconds_since(t0) < 10.0);
+    // refused at once from now on, whatever the entry point
+    t0 = std::chrono::steady_clock::now();
+    REQUIRE(sba_problem_eval_pack(p, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rot, tran, 1, 1, 1.0, pack.data()) == SBA_ERR_HIP);
+    REQUIRE(std::strstr(sba_last_error(), "poisoned") != nullptr);
+    double r2[3] = {0.1, 0.2, 0.3}, t2[3] = {0, 0, 1};
+    REQUIRE(sba_problem_solve(p, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, r2, t2, 1, 1, nullptr, nullptr) == SBA_ERR_HIP);
+    REQUIRE(sba_problem_upload(p, x.data(), x.data(), nullptr, n, SBA_STORE_F64) == SBA_ERR_HIP);
+    REQUIRE(sba_problem_set_depths(p, d12.data()) == SBA_ERR_HIP);
+    REQUIRE(sba_problem_solve_depths(p, rot, tran, 1, 1, nullptr, nullptr, nullptr) == SBA_ERR_HIP);
+    std::vector<double> groups(64 * 45);
+    REQUIRE(sba_problem_epipolar_moments(p, groups.data()) == SBA_ERR_HIP);
+    char handle[SBA_PEER_HANDLE_BYTES];
+    REQUIRE(sba_problem_peer_export(p, 2, 0, handle) == SBA_ERR_HIP);
+    REQUIRE(sba_problem_destroy(p) == SBA_ERR_HIP);          // leaks, says so, returns
+    REQUIRE(std::strstr(sba_last_error(), "leaked") != nullptr);
+    REQUIRE(seconds_since(t0) < 0.5);
+    REQUIRE(g_violations == 0);
+    g_wedged = false;
+  }
+  // ---- the d-only stage wedges in its first pass: its scratch planes must be leaked, not freed ---------------------------------
+  {
+    sba_problem* p = nullptr;
+    REQUIRE(sba_problem_create(&p, 0, nullptr) == SBA_OK);
+    REQUIRE(sba_problem_upload(p, x.data(), x.data(), d12.data(), n, SBA_STORE_F64) == SBA_OK);
+    g_wedged = true;
+    REQUIRE(sba_problem_solve_depths(p, rot, tran, 1, 1, nullptr, nullptr, nullptr) == SBA_ERR_HIP);
+    REQUIRE(sba_problem_destroy(p) == SBA_ERR_HIP);
+    REQUIRE(g_violations == 0);
+    g_wedged = false;
+  }
+  // ---- a handle that is healthy until its destroy: the bounded drain inside destroy poisons it, destroy still returns -----
+  {
+    sba_problem* p = nullptr;
+    REQUIRE(sba_problem_create(&p, 0, nullptr) == SBA_OK);
+    REQUIRE(sba_problem_upload(p, x.data(), x.data(), nullptr, n, SBA_STORE_F64) == SBA_OK);
+    g_wedged = true;
+    const auto t0 = std::chrono::steady_clock::now();
+    REQUIRE(sba_problem_destroy(p) == SBA_ERR_HIP);
+    REQUIRE(seconds_since(t0) < 10.0 && g_violations == 0);
+    g_wedged = false;
+  }
+  // ---- batch: one-launch step and the one-launch per-pair solve ---------------------------------------------------------------------
+  for (int which = 0; which < 2; ++which) {
+    sba_batch* b = nullptr;
+    const int B = 4;      // = the mock's CU count -> one block per pair, fused step, device LM
+    std::vector<size_t> off(B + 1);
+    for (int g = 0; g <= B; ++g) off[g] = static_cast<size_t>(g) * (n / B);
+    std::vector<double> rots(3 * B, 0.1), trans(3 * B, 0.2), packs(24 * B);
+    REQUIRE(sba_batch_create(&b, 0, nullptr) == SBA_OK);
+    REQUIRE(sba_batch_upload(b, x.data(), x.data(), d12.data(), off.data(), B, SBA_STORE_F64) == SBA_OK);
+    REQUIRE(sba_batch_eval(b, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rots.data(), trans.data(), nullptr, nullptr, 1.0, packs.data()) == SBA_OK);
+    g_wedged = true;
+    if (which == 0)
+      REQUIRE(sba_batch_eval(b, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rots.data(), trans.data(), nullptr, nullptr, 1.0, packs.data()) == SBA_ERR_HIP);
+    else
+      REQUIRE(sba_batch_solve(b, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rots.data(), trans.data(), nullptr, nullptr, nullptr, nullptr, nullptr) == SBA_ERR_HIP);
+    const auto t0 = std::chrono::steady_clock::now();
+    REQUIRE(sba_batch_eval(b, SBA_MODE_RT, SBA_DEPTH_PER_MATCH, rots.data(), trans.data(), nullptr, nullptr, 1.0, packs.data()) == SBA_ERR_HIP);
+    REQUIRE(std::strstr(sba_last_error(), "poisoned") != nullptr);
+    REQUIRE(sba_batch_upload(b, x.data(), x.data(), d12.data(), off.data(), B, SBA_STORE_F64) == SBA_ERR_HIP);
+    REQUIRE(sba_batch_destroy(b) == SBA_ERR_HIP);
+    REQUIRE(seconds_since(t0) < 0.5);
+    REQUIRE(g_violations == 0);
+    g_wedged = false;
+  }
+  // ---- and a healthy life cycle still frees everything (destroy returns SBA_OK) --------------------------------------------------
+  {
+    sba_problem* p = nullptr;
+    REQUIRE(sba_problem_create(&p, 0, nullptr) == SBA_OK);
+    REQUIRE(sba_problem_upload(p, x.data(), x.data(), d12.data(), n, SBA_STORE_F64) == SBA_OK);
+    REQUIRE(sba_problem_eval_pack(p, SBA_MODE_ROT, SBA_DEPTH_UNIFORM, rot, tran, 1, 1, 1.0, pack.data()) == SBA_OK);
+    REQUIRE(sba_problem_destroy(p) == SBA_OK);
+  }
+  if (g_violations) { std::fprintf(stderr, "blocking calls on a wedged device: %s\n", g_violation_names.c_str()); return 1; }
+  std::printf("wedge_harness: ok\n");
+  return 0;
+}

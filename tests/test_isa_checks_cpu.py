@@ -4,9 +4,13 @@ batch_lm_kernel is a block-wide loop -- thread 0 prepares, barrier, all threads 
 correctness needs every barrier to be executed by all 256 threads of the block in the same trip of the SAME loop.  The
 compiler once threaded a thread-0 region at the bottom of the loop into the one at its top, which left the other 255
 threads in a private inner loop: their barrier ran without lane 0 (lane 0 waits for the inner loop to end under the
-structured-control-flow lowering) and the kernel never finished.  The check: in every instantiation, each s_barrier sits
-in loop depth exactly 1, there are exactly three of them, and nothing of the kernel spills beyond the solver's 320-byte
-scratch frame.  The one-launch step kernel (no loop around its barriers) must have its barriers at depth 0."""
+structured-control-flow lowering) and the kernel never finished.  The source now rules that shape out by construction
+(one thread-0 region per trip, bracketed by two barriers of the same trip; a trip counter every thread keeps; the exit
+decision read from LDS after a barrier) -- this file is the second line of defence: in every instantiation, each
+s_barrier sits in loop depth exactly 1, there are exactly four of them, and nothing of the kernel spills beyond the
+solver's scratch frame.  The one-launch step kernel (no loop around its barriers) must have its barriers at depth 0.
+The flags are the Makefile's own (`make print-flags`), and the profiling builds (-DSBA_LM_PROFILE, -DSBA_STEP_PROFILE),
+which add clock reads to the thread-0 regions, are held to the same shape."""
 import os
 import re
 import shutil
@@ -21,17 +25,34 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 
 
-@pytest.fixture(scope="module")
-def batch_asm(tmp_path_factory):
+def _makefile_flags():
+    """The device-compile flags libsba_hip.so is built with, straight from the Makefile."""
+    r = subprocess.run(["make", "-s", "-C", CSRC, "print-flags"], check=True, capture_output=True, text=True)
+    flags = r.stdout.split()
+    assert any(f.startswith("--offload-arch=") for f in flags) and "-O3" in flags, flags
+    return flags
+
+
+def _compile_asm(tmp_path_factory, extra):
     out = tmp_path_factory.mktemp("isa") / "sba_batch_kernels.s"
     hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+    subprocess.run([hipcc, *_makefile_flags(), *extra, "-S", "--cuda-device-only",
                     os.path.join(CSRC, "sba_batch_kernels.hip"), "-o", str(out)], check=True, capture_output=True, cwd=CSRC)
     return out.read_text()
 
 
+@pytest.fixture(scope="module")
+def batch_asm(tmp_path_factory):
+    return _compile_asm(tmp_path_factory, [])
+
+
+@pytest.fixture(scope="module")
+def batch_asm_profile(tmp_path_factory):
+    return _compile_asm(tmp_path_factory, ["-DSBA_LM_PROFILE", "-DSBA_STEP_PROFILE"])
+
+
 def _functions(asm):
-    """name -> list of body lines (label line to s_endpgm)."""
+    """name -> list of body lines (label line to the function's .Lfunc_end marker; a kernel may hold several s_endpgm)."""
     funcs, name, body = {}, None, []
     for line in asm.splitlines():
         m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
@@ -40,7 +61,7 @@ def _functions(asm):
             continue
         if name is not None:
             body.append(line)
-            if "s_endpgm" in line:
+            if line.startswith(".Lfunc_end"):
                 funcs[name] = body
                 name = None
     return funcs
@@ -74,7 +95,20 @@ def test_lm_kernel_barriers_are_block_uniform(batch_asm):
     assert len(lm) >= 20, len(lm)            # modes x depth x store x kind x loss instantiations
     for name, body in lm.items():
         d = _barrier_depths(body)
-        assert d == [1, 1, 1], (name, d)
+        assert d == [1, 1, 1, 1], (name, d)
+
+
+def test_profile_builds_keep_the_shape(batch_asm_profile):
+    funcs = _functions(batch_asm_profile)
+    lm = {k: v for k, v in funcs.items() if "batch_lm_kernel" in k}
+    st = {k: v for k, v in funcs.items() if "batch_step_kernel" in k}
+    assert len(lm) >= 20 and len(st) >= 20, (len(lm), len(st))
+    for name, body in lm.items():
+        d = _barrier_depths(body)
+        assert d == [1, 1, 1, 1], (name, d)
+    for name, body in st.items():
+        d = _barrier_depths(body)
+        assert d and all(x == 0 for x in d), (name, d)
 
 
 def test_step_kernel_barriers_outside_loops(batch_asm):
