@@ -13,8 +13,10 @@ correspondences sharded 8xMI355X") = 12.5M of the same correspondences per GPU, 
 At N = 1 the line also carries `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
 child run of `--workload c5` after the timed region (`--no-c5-leg` skips it), and `stages`: the 8-point initial guess and the
 bounded d-only stage of `solve_problem` on the resident problem (`--no-stage-leg`).
-At N > 1 the line also carries `peer_trial`: after the quoted measurement, the same K steps once more over the direct
-peer exchange -- a second figure, never the quoted `value` (`--no-peer-trial` skips it).
+At N > 1, only on request (`--peer-trial` / SBA_BENCH_PEER_TRIAL=1), the line also carries `peer_trial`: after the
+quoted measurement -- whose line is then first written to stderr, so it survives whatever the trial does -- the same K
+steps once more over the direct peer exchange: a second figure, never the quoted `value`.  Off by default until the
+peer path has one cross-device run behind it.
 A *step* is one pass of the hot path over the resident correspondences exactly as one LM iteration needs it: sweep
 kernel (residual + analytic Jacobian + Huber + reduction), finalize kernel, the all-reduce when N > 1, and the pack
 published to and awaited by the host.  Weak scaling: per-GPU work is fixed as N grows, no data-path communication
@@ -79,8 +81,14 @@ def parse():
                     help="N = 1: skip the initial-guess / d-only-stage figures (`stages` in the line)")
     ap.add_argument("--no-c5-leg", action="store_true",
                     help="N = 1: skip the config-C5 figures (`c5` in the line: a child run of --workload c5)")
-    ap.add_argument("--no-peer-trial", action="store_true",
-                    help="N > 1: skip the second, un-quoted measurement over the direct xGMI peer exchange")
+    ap.add_argument("--peer-trial", action="store_true",
+                    help="N > 1: after the quoted measurement take a second, un-quoted one over the direct xGMI peer "
+                         "exchange (opt-in; also SBA_BENCH_PEER_TRIAL=1)")
+    ap.add_argument("--no-peer-trial", action="store_true", help="(accepted for older command lines; the trial is off by default)")
+    ap.add_argument("--no-cold-leg", action="store_true",
+                    help="skip the W + K steps taken BEFORE the pre-conditioning (`cold` in the line)")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="N = 1: skip the K steps at 12.5M correspondences (`scaling_reference`: the per-GPU size of N > 1)")
     return ap.parse_args()
 
 
@@ -367,6 +375,31 @@ def c5_leg(steps: int, warmup: int):
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
 
+def scaling_reference(api, synthetic, c, seed, device_index, a):
+    """N = 1 only, after the timed region: the same K host-synchronous steps at 12.5M correspondences -- the per-GPU size
+    every rank of an N > 1 run holds (one GPU's shard of config C4).  The quoted N = 1 value is config C3's 10M; a weak-
+    scaling curve whose N = 1 point has less work per GPU than its N > 1 points flatters the efficiency (larger sweeps
+    amortise the launch better), so this is the N = 1 point to divide by."""
+    import numpy as np
+    try:
+        n_ref = 12_500_000
+        extra = synthetic.full_rt(n_ref - a.n, seed=seed, shard=1)       # same two-view geometry, further points
+        x1, x2, d12 = (np.concatenate([getattr(c, k), getattr(extra, k)]) for k in ("x1", "x2", "d12"))
+        with api.Problem(device_index) as q:
+            q.upload(x1, x2, d12)
+            del x1, x2, d12
+            q.eval_launch_times(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, repeat=200)
+            q.eval_steps(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, steps=max(a.warmup, 1))
+            _, seconds = q.eval_steps(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, steps=a.steps)
+            _, _, sweep_ms = q.eval_timed(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, repeat=a.steps)
+        return {"ok": True, "correspondences_per_gpu": n_ref, "value": n_ref * a.steps / seconds, "ms_per_step": seconds / a.steps * 1e3,
+                "kernel_ms": sweep_ms, "frac": n_ref * 64 / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "what": "N = 1 at the per-GPU size of the N > 1 runs (12.5M = one GPU's shard of config C4): the reference "
+                        "point of the weak-scaling curve"}
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
+
 def peer_trial(p, transport, dist, torch, run_steps, barrier, ref_pack, world, n):
     """N > 1, after the quoted measurement: the same K steps over the direct xGMI peer exchange (tools: DESIGN.md 5).
     Never the quoted `value`; it exists so that the first multi-GPU run also says what one-launch peer stores cost
@@ -490,6 +523,24 @@ def main():
     # W warm-up steps, then EXACTLY K steps, each host-synchronous (launch -> reduction -> all-reduce -> result on
     # the host) and driven from C++ like the LM loop drives them (sba_problem_eval_steps), bracketed by barriers.
     barrier()   # ranks generate and upload their shards at different speeds: enter the first exchange together
+    # `cold`: the command line taken literally -- W warm-up + K timed steps straight after the upload, BEFORE any
+    # pre-conditioning (what round 1's driver run measured: the K steps fall into the clock dip after the first ~1.5 ms
+    # of load).  Reported beside the quoted value, never instead of it.
+    cold = None
+    if not a.no_cold_leg:
+        if a.warmup > 0:
+            p.eval_steps(mode, rot, tran, depth_mode=depth_mode, steps=a.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        p.eval_steps(mode, rot, tran, depth_mode=depth_mode, steps=a.steps)
+        barrier()
+        cold_elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([cold_elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cold_elapsed = float(t.item())
+        cold = {"value": a.n * world * a.steps / cold_elapsed, "ms_per_step": cold_elapsed / a.steps * 1e3,
+                "what": f"{a.warmup} warm-up + {a.steps} timed steps straight after the upload, before the pre-conditioning"}
     # Un-timed, disclosed pre-conditioning (see the module docstring): the same sweep kernel, no exchange, not a step.
     precond = {"sweeps": 0, "ms": 0.0}
     if a.precondition_ms > 0:
@@ -521,8 +572,17 @@ def main():
     p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)         # first call: one-time costs
     r_s, t_s, summ = p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)
     barrier()
+    want_trial = world > 1 and not a.no_peer_trial and (a.peer_trial or os.environ.get("SBA_BENCH_PEER_TRIAL", "0") == "1")
     trial = None
-    if world > 1 and not a.no_peer_trial and os.environ.get("SBA_BENCH_PEER_TRIAL", "1") != "0":
+
+    def headline():
+        total = a.n * world
+        return {"metric": "residual+Jacobian evals/sec", "value": total * a.steps / elapsed, "unit": "evals/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "allreduce": transport}
+    if want_trial:
+        if rank == 0:      # the quoted figure is on record before the un-quoted leg touches the transport
+            print("bench.py: quoted measurement before the peer trial: " + json.dumps(headline()), file=sys.stderr, flush=True)
+
         def run_steps(k):
             k = a.steps if k is None else k
             return p.eval_steps(mode, rot, tran, depth_mode=depth_mode, steps=k)[0], k
@@ -538,7 +598,9 @@ def main():
             "metric": "residual+Jacobian evals/sec", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic" + (" (ONE-GPU REHEARSAL of the multi-rank path: not a measurement)" if rehearsal else ""),
+            # the arithmetic type of the path: always f64; with --store f32 the resident unit vectors are f32
+            "dtype": "f64" if a.store == "f64" else "f64 arithmetic on f32-stored unit vectors",
+            "data": "synthetic" + (" (ONE-GPU REHEARSAL of the multi-rank path: not a measurement)" if rehearsal else ""),
             "config": {"workload": ("10M synthetic unit-sphere correspondences per GPU, full R|t sweep, per-match "
                                     "depths (BASELINE config C3)" if rt and a.n == 10_000_000 and world == 1 else
                                     "12.5M synthetic unit-sphere correspondences per GPU = one GPU's shard of BASELINE "
@@ -560,7 +622,11 @@ def main():
                          "kernel_ms_per_launch": [round(float(x), 4) for x in per_launch[:32]],
                          "algorithmic_bytes_per_launch": a.n * bytes_per_eval},
             "preconditioning": {**precond, "what": "un-timed sweeps of the same kernel before the warm-up steps "
-                                                   "(clock dip after the first ~1.5 ms of load; --precondition-ms)"},
+                                                   "(clock dip after the first ~1.5 ms of load; --precondition-ms)",
+                                # everything the device ran between the upload and the first timed step
+                                "launches_before_the_timed_region": precond["sweeps"] + a.warmup
+                                                                    + (0 if cold is None else a.warmup + a.steps)},
+            "cold": cold,
             "kernel_only_evals_per_s": a.n / (sweep_ms * 1e-3),
             "device_step_ms": step_ms,
             "lm": {"iters_per_s": summ.num_iterations / summ.seconds_total if summ.seconds_total > 0 else None,
@@ -585,6 +651,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c, mode, rt, a.cpu_sample, a.cpu_seconds)
     if rank == 0:
+        if world == 1 and not rehearsal and rt and a.n == 10_000_000 and a.store == "f64" and not a.no_scaling_reference:
+            out["scaling_reference"] = scaling_reference(api, synthetic, c, seed, device_index, a)
         if world == 1 and not rehearsal and not a.no_stage_leg and rt:
             out["stages"] = stage_leg(p, c, a.n)
         if world == 1 and not rehearsal and not a.no_c5_leg and rt and a.store == "f64":

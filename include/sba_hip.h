@@ -369,8 +369,9 @@ int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* r
 int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
                                  const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms);
 /* The same measurement on the dominant kernel of the step this batch really runs: with one block per pair the whole
- * step is ONE launch (batch_step_kernel: per-pair state, sweep, fold, conversion; timed here with its publication to
- * the host switched off), otherwise the batched sweep kernel as above.  sba_batch_step_is_fused: 1 / 0 (negative =
+ * step is ONE launch (batch_step_kernel: per-pair state read from mapped host memory, sweep, fold, conversion, packs and
+ * sequence word published to the host -- launched here exactly as a step launches it, only the host does not wait
+ * between launches), otherwise the batched sweep kernel as above.  sba_batch_step_is_fused: 1 / 0 (negative =
  * error) -- which of the two it is (SBA_BATCH_FUSED_STEP=0 in the environment keeps the three-kernel chain).        */
 int sba_batch_step_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
                                 const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms);

@@ -422,8 +422,9 @@ int sba_batch_eval_timed(sba_batch* b, int mode, int depth_mode, const double* r
 
 namespace {
 // `repeat` launches of one kernel with a HIP event between every two.  step_kernel = false: the bare batch_sweep_kernel;
-// true: the dominant kernel of the step this batch really runs -- batch_step_kernel (publication off: no ticket, no
-// host stores) when the step is fused, batch_sweep_kernel otherwise.
+// true: the dominant kernel of the step this batch really runs -- batch_step_kernel EXACTLY as a step launches it (state
+// read from mapped host memory, packs and sequence word published to the host: the kernel rocprofv3 sees in a step) when
+// the step is fused, batch_sweep_kernel otherwise.  The only difference from a step: the host does not wait in between.
 int kernel_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran, const double* d1,
                         const double* d2, double huber_delta, int repeat, float* launch_ms, bool step_kernel) {
   int rc = check_batch_args(b, mode, depth_mode, rot, tran);
@@ -449,7 +450,8 @@ int kernel_launch_times(sba_batch* b, int mode, int depth_mode, const double* ro
   for (int i = 0; i < repeat; ++i) {
     if (fused)
       SBA_TRY_HIP(sba::launch_batch_step_fused(mode, depth_mode, b->store, b->kind, huber_delta, pl, b->state_host_dev,
-                                               b->desc_dev, b->num_pairs, b->packs_dev, nullptr, b->lm_ticket, 0, b->stream));
+                                               b->desc_dev, b->num_pairs, b->packs_dev, b->packs_host_dev, b->lm_ticket,
+                                               ++b->seq, b->stream));
     else
       SBA_TRY_HIP(sba::launch_batch_sweep_only(mode, depth_mode, b->store, b->kind, huber_delta > 0.0, pl, b->params_dev,
                                                b->desc_dev, b->num_pairs, b->bpp, b->partials, b->stream));

@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "sba_problem.hpp"
 
@@ -178,6 +180,32 @@ int sba_problem_comm_destroy(sba_problem* p) {
 }
 
 // ---- direct peer exchange ---------------------------------------------------------------------------------------
+namespace {
+// Inboxes exported by THIS process.  A process may host several ranks (one host thread and one sba_problem per GPU of a
+// node -- or, in tests, several ranks on one GPU): hipIpcOpenMemHandle refuses a handle of the opening process itself, so
+// peers that live in the same process are connected by plain device pointer (with peer access enabled when they sit on
+// different devices); everything else about the exchange is unchanged.
+struct LocalInbox { hipIpcMemHandle_t handle; double* ptr; int device; };
+std::mutex g_local_mutex;
+std::vector<LocalInbox> g_local_inboxes;
+
+void register_local_inbox(const hipIpcMemHandle_t& h, double* ptr, int device) {
+  std::lock_guard<std::mutex> lock(g_local_mutex);
+  g_local_inboxes.push_back(LocalInbox{h, ptr, device});
+}
+void unregister_local_inbox(const double* ptr) {
+  std::lock_guard<std::mutex> lock(g_local_mutex);
+  g_local_inboxes.erase(std::remove_if(g_local_inboxes.begin(), g_local_inboxes.end(),
+                                       [ptr](const LocalInbox& b) { return b.ptr == ptr; }), g_local_inboxes.end());
+}
+bool find_local_inbox(const hipIpcMemHandle_t& h, LocalInbox* out) {
+  std::lock_guard<std::mutex> lock(g_local_mutex);
+  for (const LocalInbox& b : g_local_inboxes)
+    if (std::memcmp(&b.handle, &h, sizeof(h)) == 0) { *out = b; return true; }
+  return false;
+}
+}  // namespace
+
 int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SBA_PEER_HANDLE_BYTES]) {
   if (!p || !handle) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
   SBA_REFUSE_POISONED(p);
@@ -212,6 +240,7 @@ int sba_problem_peer_export(sba_problem* p, int nranks, int rank, char handle[SB
     return sba::set_error(SBA_ERR_COMM, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
   }
   std::memcpy(handle, &h, SBA_PEER_HANDLE_BYTES);
+  register_local_inbox(h, p->inbox, p->device);
   p->peers.nranks = nranks;
   p->peers.rank = rank;
   p->shard_rank = rank;
@@ -228,6 +257,20 @@ int sba_problem_peer_connect(sba_problem* p, const char* handles) {
     if (r == p->peers.rank) { p->peers.inbox[r] = p->inbox; continue; }
     hipIpcMemHandle_t h;
     std::memcpy(&h, handles + static_cast<size_t>(r) * SBA_PEER_HANDLE_BYTES, SBA_PEER_HANDLE_BYTES);
+    LocalInbox local;
+    if (find_local_inbox(h, &local)) {      // rank r lives in this process: its inbox by pointer, nothing to open
+      if (local.device != p->device) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(local.device, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+          (void)sba_problem_peer_disable(p);
+          return sba::set_error(SBA_ERR_COMM, "hipDeviceEnablePeerAccess(device %d, for rank %d) failed: %s", local.device, r,
+                                hipGetErrorString(pe));
+        }
+        (void)hipGetLastError();
+      }
+      p->peers.inbox[r] = local.ptr;
+      continue;
+    }
     void* ptr = nullptr;
     const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) {
@@ -254,7 +297,7 @@ int sba_problem_peer_disable(sba_problem* p) {
     if (o) (void)hipIpcCloseMemHandle(o);
     o = nullptr;
   }
-  if (p->inbox) (void)hipFree(p->inbox);
+  if (p->inbox) { unregister_local_inbox(p->inbox); (void)hipFree(p->inbox); }
   p->inbox = nullptr;
   p->peer_ready = false;
   return SBA_OK;

@@ -76,6 +76,61 @@ def _try_peer(problem: api.Problem, torch, dist) -> bool:
     return False
 
 
+def attach_peer_local_ranks(problems, ranks, world: int, selftest_rounds: int = 8) -> bool:
+    """The direct peer exchange for a process that hosts SEVERAL ranks -- one ``Problem`` (and, while sweeping, one host
+    thread) per rank: a host that drives all GPUs of a node from one process, or a rehearsal of the node's full width
+    of 8 ranks inside the few processes a one-GPU box admits.  ``ranks[i]`` is the global rank of ``problems[i]``; every
+    process of the torch.distributed group must host the same number of ranks, ``world`` in all.  Ranks of one process
+    reach each other's inbox by device pointer (the shim recognises its own handles), all others through HIP IPC.
+    Control collectives are issued from the calling thread only; the self-test exchanges run one thread per rank (an
+    exchange blocks until every rank of the world has arrived).  Returns True when every rank of the world is
+    connected and passed the self-test; otherwise every problem is detached again and False is returned."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    ok = world <= 8 and len(problems) == len(ranks) and len(ranks) * dist.get_world_size() == world
+    mine = []
+    if ok:
+        try:
+            mine = [(int(r), p.peer_export(world, int(r))) for p, r in zip(problems, ranks)]
+        except api.SbaError:
+            ok = False
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, mine)
+    table = dict(kv for part in gathered for kv in part)
+    ok = ok and sorted(table) == list(range(world))
+    if _all_agree(torch, dist, ok):
+        blob = b"".join(table[r] for r in range(world))
+        try:
+            for p in problems:
+                p.peer_connect(blob)
+        except api.SbaError:
+            ok = False
+    else:
+        ok = False
+    if _all_agree(torch, dist, ok):
+        passed = [False] * len(problems)
+
+        def selftest(i):
+            try:
+                passed[i] = bool(problems[i].peer_selftest(selftest_rounds))
+            except api.SbaError:
+                passed[i] = False
+        threads = [threading.Thread(target=selftest, args=(i,)) for i in range(len(problems))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        ok = all(passed)
+    else:
+        ok = False
+    if _all_agree(torch, dist, ok):
+        return True
+    for p in problems:
+        p.peer_disable()
+    return False
+
+
 def _try_rccl(problem: api.Problem, torch, dist) -> bool:
     world, rank = dist.get_world_size(), dist.get_rank()
     # ncclCommInitRank is itself a collective: a rank that cannot even load librccl would leave the others blocked

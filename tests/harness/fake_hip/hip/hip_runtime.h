@@ -8,7 +8,7 @@
 #include <cstdint>
 
 typedef int hipError_t;
-enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorNoDevice = 100, hipErrorUnknown = 999 };
+enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorNoDevice = 100, hipErrorPeerAccessAlreadyEnabled = 704, hipErrorUnknown = 999 };
 typedef struct fake_hip_stream* hipStream_t;
 typedef struct fake_hip_event* hipEvent_t;
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; };
@@ -47,3 +47,4 @@ hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*);
 hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned);
 hipError_t hipIpcCloseMemHandle(void*);
+hipError_t hipDeviceEnablePeerAccess(int, unsigned);

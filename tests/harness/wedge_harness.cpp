@@ -60,6 +60,7 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; r
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorUnknown; }
 hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorUnknown; }
 hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 
 // ---- stub kernel launchers (the .hip files are not part of this build) ---------------------------------------------------
 namespace sba {

@@ -160,12 +160,19 @@ def _rank(rank, world, port, q, case):
         lo, hi = syn.shard_range(n, rank, world)
         exchanges = []
 
-        def reduce_fn(sums, maxima):                      # ONE exchange per pass: 7 sums (SUM) + 2 maxima (MAX)
-            a, b = torch.from_numpy(sums.copy()), torch.from_numpy(maxima.copy())
-            dist.all_reduce(a, op=dist.ReduceOp.SUM)
-            dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        def reduce_fn(sums, maxima):
+            # ONE exchange per pass, in the product's own wire format (csrc/sba_depth.hip depth_finalize_kernel with
+            # gather_slot = rank, csrc/sba_stages.cpp): a 24-double pack for a SUM all-reduce -- the seven sums in slots
+            # 0..6, and the two max-norms, which a SUM cannot carry, as one slot per rank each (8 + rank, 16 + rank; zeros
+            # elsewhere), whose maxima every rank takes on the host.  At most 8 ranks: rank 7 fills slots 15 and 23.
+            assert world <= 8 and len(sums) == 7 and len(maxima) == 2
+            pack = np.zeros(24)
+            pack[:7] = sums
+            pack[8 + rank], pack[16 + rank] = maxima
+            t = torch.from_numpy(pack)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
             exchanges.append(1)
-            return a.numpy(), b.numpy()
+            return pack[:7].copy(), np.array([pack[8:8 + world].max(), pack[16:16 + world].max()])
         shard = T.EmulatedShard(cs.x1[lo:hi], cs.x2[lo:hi], cs.rot_init, cs.tran_init, np.full((hi - lo, 2), d0), lam, c)
         d, s, status, passes = T.drive(shard, reduce_fn)
         q.put((rank, lo, hi, d, s.termination, s.num_iterations, s.num_successful_steps, s.num_line_search_steps, s.final_cost,
@@ -177,15 +184,17 @@ def _rank(rank, world, port, q, case):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("case", [(500, 6, 1.0, 1.0, 1.0), (300, 12, 2.0, 1.0, 1.0)], ids=["with_contraction", "plain"])
-def test_depth_stage_sharded_gloo_world2_matches_single(oracle, case):
+def test_depth_stage_sharded_gloo_matches_single(oracle, case, world):
+    """world = 8 is the node's width (BASELINE config C4): the last rank deposits its max-norms in pack slots 15 and 23."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, case)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, q, case)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
     [p.join(30) for p in procs]
@@ -200,4 +209,4 @@ def test_depth_stage_sharded_gloo_world2_matches_single(oracle, case):
         assert np.abs(d - dref[lo:hi]).max() <= 1e-7 * max(1.0, np.abs(dref).max())
         assert abs(cost - sref.final_cost) <= 1e-10 * sref.final_cost
         assert exchanges == passes                         # exactly one exchange per pass
-    assert res[0][8] == res[1][8] and res[0][10] == res[1][10]   # bit-identical reduced cost, lock-step passes
+    assert len(res) == world and all(r[8] == res[0][8] and r[10] == res[0][10] for r in res)   # bit-identical reduced cost, lock-step passes

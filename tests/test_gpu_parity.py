@@ -222,6 +222,72 @@ def test_full_size_properties(oracle, n, gen, mode, dm):
         assert s.termination.startswith("CONVERGENCE") and np.abs(r - c.rot_true).max() < 5e-3
 
 
+def test_config_c4_full_size_on_one_gpu_and_the_eight_shard_identity(oracle):
+    """BASELINE config C4: 100 M rotation-only correspondences, sharded 8 x 12.5 M with ONE all-reduce of the pack per
+    sweep.  All of it fits one MI355X (6 planes x 800 MB = 4.8 GB of 288 GB), so the identity the sharding rests on --
+    one residual block per match, every block sharing init_rot (reference spherical_bundle_adjuster.cpp:921-945), hence
+    H, g, cost are plain sums over matches -- is checked at the real size: the packs of the 8 contiguous shards
+    (synthetic.shard_range, what `bench.py --gpus 8` gives its ranks: 12.5 M each) sum to the full problem's pack to
+    1e-12, outlier counts exactly.  Plus determinism, factored == explicit, the oracle on a bounded prefix, and the LM
+    on a 12.5 M shard converging to the generating rotation.  The 4.8 GB of synthetic input are drawn ON the device
+    (torch, seeded: numpy needs ~2 minutes of host time for them) with synthetic.rotation_only's recipe and handed
+    over with sba_problem_upload_device -- the C-ABI's device-resident upload, cv::Point3d layout."""
+    import torch
+    world, per = 8, 12_500_000
+    n = world * per
+    c0 = synthetic.rotation_only(8, seed=synthetic.BASE_SEED + 3)        # ground truth + start point of the geometry
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(synthetic.BASE_SEED + 3)
+    R = torch.tensor(synthetic.rodrigues(c0.rot_true), dtype=torch.float64, device=dev)
+    x1 = torch.randn((n, 3), dtype=torch.float64, device=dev, generator=g)
+    x1 /= x1.norm(dim=1, keepdim=True)
+    x2 = x1 @ R.T
+    x2 += 1e-3 * torch.randn((n, 3), dtype=torch.float64, device=dev, generator=g)
+    x2 /= x2.norm(dim=1, keepdim=True)
+    out = torch.rand(n, device=dev, generator=g) < 0.05                   # 5 % outliers: uniform points on the sphere
+    rnd = torch.randn((int(out.sum().item()), 3), dtype=torch.float64, device=dev, generator=g)
+    x2[out] = rnd / rnd.norm(dim=1, keepdim=True)
+    del rnd, out
+    torch.cuda.synchronize()
+    assert [synthetic.shard_range(n, r, world) for r in range(world)] == [(r * per, (r + 1) * per) for r in range(world)]
+    mode, dm = api.MODE_ROT, api.DEPTH_UNIFORM
+
+    def upload(p, lo, hi):
+        p.upload_device(x1.data_ptr() + 24 * lo, x2.data_ptr() + 24 * lo, None, hi - lo)
+
+    with api.Problem(0) as p:
+        upload(p, 0, n)
+        assert p.size == n
+        p.set_kernel(api.KERNEL_FACTORED)
+        full = p.eval_pack(mode, c0.rot_init, c0.tran_init, depth_mode=dm)
+        assert np.array_equal(full, p.eval_pack(mode, c0.rot_init, c0.tran_init, depth_mode=dm))      # deterministic
+        p.set_kernel(api.KERNEL_EXPLICIT)
+        full_explicit = p.eval_pack(mode, c0.rot_init, c0.tran_init, depth_mode=dm)
+        p.set_kernel(api.KERNEL_FACTORED)
+        assert np.abs(full - full_explicit).max() <= REL_TOL_F64 * np.abs(full).max() and full[23] == full_explicit[23]
+        assert abs(full[23] / n - 0.05) < 0.01                          # the outliers sit in Huber's linear region
+        at_truth = p.eval_pack(mode, c0.rot_true, c0.tran_true, depth_mode=dm)
+        assert at_truth[22] < full[22]
+        total = np.zeros(24)
+        for r in range(world):
+            lo, hi = synthetic.shard_range(n, r, world)
+            upload(p, lo, hi)
+            part = p.eval_pack(mode, c0.rot_init, c0.tran_init, depth_mode=dm)
+            assert np.array_equal(part, p.eval_pack(mode, c0.rot_init, c0.tran_init, depth_mode=dm))
+            total += part
+            if r == world - 1:       # the shard rank 7 of the 8-GPU run holds: the LM converges on it
+                rr, tt, s = p.solve(mode, c0.rot_init, c0.tran_init, depth_mode=dm)
+                assert s.termination.startswith("CONVERGENCE") and np.abs(rr - c0.rot_true).max() < 5e-3
+        assert np.abs(total - full).max() <= REL_TOL_F64 * np.abs(full).max()
+        assert total[23] == full[23]                                   # outlier counts are exact integers
+        k = 200_000
+        upload(p, 0, k)
+        head = p.eval_pack(mode, c0.rot_init, c0.tran_init, depth_mode=dm)
+    h1, h2 = x1[:k].cpu().numpy(), x2[:k].cpu().numpy()
+    ref = pack_from_eval(mode, oracle.evaluate(mode, h1, h2, c0.rot_init, c0.tran_init))
+    assert np.abs(head - ref).max() <= REL_TOL_F64 * np.abs(ref).max()
+
+
 # ---- d-only stage (first stage of solve_problem) ----------------------------------------------------------
 @pytest.mark.parametrize("n,store", [(1, api.STORE_F64), (65, api.STORE_F64), (5000, api.STORE_F64),
                                      (5000, api.STORE_F32), (200001, api.STORE_F64)])

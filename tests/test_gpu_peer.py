@@ -18,49 +18,97 @@ N = 60001
 LS_N = 500
 
 
-def _worker(rank, world, port, q):
+def _worker(proc, nproc, local, port, q):
+    """One process hosting `local` ranks (global ranks proc * local ... + local - 1), one Problem and one thread each.
+    local = 1 is the production shape (one process per rank, distributed.attach); local = 2 puts the node's full width of
+    8 ranks into the 4 processes a one-GPU box admits (at most 6 may use the card at once)."""
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import threading
+    import traceback
     import torch
     import torch.distributed as dist
     import numpy as np
     from spherical_bundle_adjuster_amd import api as A, distributed, synthetic as syn
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=proc, world_size=nproc)
+    world = nproc * local
+    ranks = [proc * local + i for i in range(local)]
+    out = [None] * local
+
+    def attach(problems):
+        if local == 1:
+            return distributed.attach(problems[0], transport="peer")
+        return "xgmi-peer" if distributed.attach_peer_local_ranks(problems, ranks, world) else "FAILED"
+
+    def in_threads(fn):
+        errs = []
+
+        def run(i):
+            try:
+                fn(i)
+            except Exception:
+                errs.append(traceback.format_exc())
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(local)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        if errs:
+            raise RuntimeError(errs[0])
     try:
         torch.cuda.set_device(0)
         c = syn.full_rt(N, seed=77)
-        lo, hi = syn.shard_range(N, rank, world)
-        with A.Problem(0) as p:
+        spans = [syn.shard_range(N, r, world) for r in ranks]
+        problems = [A.Problem(0) for _ in ranks]
+        for p, (lo, hi) in zip(problems, spans):
             p.upload(c.x1[lo:hi], c.x2[lo:hi], c.d12[lo:hi])
-            used = distributed.attach(p, transport="peer")
+        used = attach(problems)
+        res1 = [None] * local
+
+        def body1(i):
+            p = problems[i]
             packs = [p.eval_pack(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH) for _ in range(5)]
             packs.append(p.eval_steps(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH, steps=20)[0])
             r, t, s = p.solve(A.MODE_RT, c.rot_init, c.tran_init, depth_mode=A.DEPTH_PER_MATCH)
             tr, _, _ = p.solve(A.MODE_ROT, c.rot_init, c.tran_init, 1.1, 0.9)
-            # d-only stage on the sharded problem: six global reductions exchanged per pass, identical step logic
+            # d-only stage on the sharded problem: nine global reductions exchanged per pass (the two max-norms in pack
+            # slots 8 + rank and 16 + rank: rank 7 reaches slots 15 and 23), identical step logic on every rank
             d, sd = p.solve_depths(c.rot_true, c.tran_true)
-            # 8-point initial guess on the sharded problem: group moments all-reduced, same guess on every rank
+            # 8-point initial guess on the sharded problem: 64 x 45 group moments all-reduced (120 back-to-back
+            # exchanges), same guess on every rank
             gm = p.epipolar_moments()
             eul, tg, ncand = p.initial_guess(80, 0.25, 5)
-            dist.barrier()
+            res1[i] = (packs, r, t, s.num_iterations, tr, d, sd, (gm, eul, tg, ncand))
+        in_threads(body1)
+        dist.barrier()
+        for p in problems:
             p.peer_disable()
+            p.close()
         # ... and a small problem whose first full step fails Armijo (500 matches, start d = 1: one contraction to
         # a = 0.49): the line search's extra passes are sharded and all-reduced like every other pass
         c2 = syn.full_rt(LS_N, seed=6)
-        lo2, hi2 = syn.shard_range(LS_N, rank, world)
-        with A.Problem(0) as p2:
-            p2.upload(c2.x1[lo2:hi2], c2.x2[lo2:hi2], np.ones((hi2 - lo2, 2)))
-            distributed.attach(p2, transport="peer")
-            d_ls, sd_ls = p2.solve_depths(c2.rot_init, c2.tran_init)
-            dist.barrier()
-            p2.peer_disable()
-        q.put((rank, used, packs, r, t, s.num_iterations, tr,
-               (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost, d_ls, sd_ls.num_iterations, sd_ls.num_line_search_steps,
-                sd_ls.final_cost, lo2, hi2),
-               (gm, eul, tg, ncand)))
-    except Exception as e:      # surface the failure in the parent instead of a silent timeout
-        import traceback
-        q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None, None, None))
+        spans2 = [syn.shard_range(LS_N, r, world) for r in ranks]
+        problems2 = [A.Problem(0) for _ in ranks]
+        for p, (lo2, hi2) in zip(problems2, spans2):
+            p.upload(c2.x1[lo2:hi2], c2.x2[lo2:hi2], np.ones((hi2 - lo2, 2)))
+        used2 = attach(problems2)
+        res2 = [None] * local
+
+        def body2(i):
+            res2[i] = problems2[i].solve_depths(c2.rot_init, c2.tran_init)
+        in_threads(body2)
+        dist.barrier()
+        for p in problems2:
+            p.peer_disable()
+            p.close()
+        for i, rank in enumerate(ranks):
+            packs, r, t, iters, tr, d, sd, guess = res1[i]
+            d_ls, sd_ls = res2[i]
+            (lo, hi), (lo2, hi2) = spans[i], spans2[i]
+            q.put((rank, used if used == used2 else "FAILED", packs, r, t, iters, tr,
+                   (lo, hi, d, sd.num_iterations, sd.termination, sd.final_cost, d_ls, sd_ls.num_iterations,
+                    sd_ls.num_line_search_steps, sd_ls.final_cost, lo2, hi2), guess))
+    except Exception:      # surface the failure in the parent instead of a silent timeout
+        for rank in ranks:
+            q.put((rank, "ERROR", traceback.format_exc(), None, None, None, None, None, None))
     finally:
         dist.destroy_process_group()
 
@@ -74,18 +122,23 @@ def _shard_moments(c, world):
             yield p.epipolar_moments()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_peer_exchange_processes_on_one_gpu(world):
+@pytest.mark.parametrize("nproc,local", [(2, 1), (4, 1), (4, 2)])
+def test_peer_exchange_processes_on_one_gpu(nproc, local):
+    """world = nproc x local ranks on ONE GPU.  (4, 2) is the node's real width: 8 ranks -- kMaxPeers reached exactly,
+    the sharded d-only stage's max-norm slots 8 + 7 and 16 + 7, the 120-exchange moment all-reduce against 8 pollers --
+    in 4 processes of 2 ranks each, because a box of this pool admits at most 6 processes on its card."""
     import torch.multiprocessing as mp
+    world = nproc * local
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, nproc, local, port, q)) for r in range(nproc)]
     [p.start() for p in procs]
-    res = sorted([q.get(timeout=240) for _ in procs], key=lambda x: x[0])
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
     [p.join(60) for p in procs]
+    assert [r[0] for r in res] == list(range(world))
     for r in res:
         assert r[1] == "xgmi-peer", r[2] if r[1] == "ERROR" else r[1]
     c = synthetic.full_rt(N, seed=77)
@@ -133,7 +186,8 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     env = dict(os.environ, SBA_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup",
-           "2", "--matches", "200000", "--transport", "peer"]    # RCCL (the default) cannot place two ranks on ONE device
+           "2", "--matches", "200000", "--transport", "peer",    # RCCL (the default) cannot place two ranks on ONE device
+           "--peer-trial"]                                        # the un-quoted second measurement is opt-in
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -145,9 +199,37 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     assert b["lm"]["termination"].startswith("CONVERGENCE") and "cpu_baseline" not in b
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in b["roofline"]
-    # the second, un-quoted measurement over the peer exchange (detach -> attach -> self-test -> K steps) went through
+    assert b["cold"]["value"] > 0 and b["preconditioning"]["launches_before_the_timed_region"] >= 2 + 2 + 10
+    # the second, un-quoted measurement over the peer exchange (detach -> attach -> self-test -> K steps) went through,
+    # and the quoted figure was on record (stderr) before it started
     t = b["peer_trial"]
     assert t["ok"] and t["ms_per_step"] > 0 and t["max_rel_diff_to_quoted_pack"] <= 1e-12, t
+    pre = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py: quoted measurement before the peer trial: ")]
+    assert len(pre) == 1 and json.loads(pre[0].split(": ", 2)[2])["value"] == b["value"]
+
+
+def test_bench_four_rank_rehearsal_default_flags(tmp_path):
+    """The driver's own N = 4 command line (no transport / trial flags) in the one-GPU rehearsal mode, except that the
+    transport must be named: RCCL cannot place several ranks on one device.  Four ranks + this process = 5 processes on
+    the card (the pool admits 6), so the node's width of 8 cannot be rehearsed as processes -- the 8-rank exchange is
+    covered by test_peer_exchange_processes_on_one_gpu[4-2].  No peer trial unless asked for."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SBA_BENCH_ONE_GPU="1", SBA_TRANSPORT="peer")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "4", "--steps", "10", "--warmup",
+           "2", "--matches", "100000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 4 and b["config"]["allreduce"] == "xgmi-peer" and b["peer_trial"] is None
+    assert abs(b["value"] - 4 * 100000 * 10 / (b["ms_per_step"] * 1e-3 * 10)) <= 1e-6 * b["value"]
+    assert b["lm"]["termination"].startswith("CONVERGENCE")
 
 
 def test_bench_c5_two_rank_rehearsal(tmp_path):

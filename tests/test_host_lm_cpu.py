@@ -107,24 +107,26 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_gloo_world2_matches_single(oracle):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_gloo_matches_single(oracle, world):
+    """world = 8: the width of the node BASELINE config C4 shards over (ragged shards of 376 and 369 matches)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=180) for _ in procs])
     [p.join(60) for p in procs]
     c = synthetic.full_rt(3001, seed=51)
     r1, t1, s1, rc1 = harness_solve(2, c.rot_init, c.tran_init, _oracle_evaluator(oracle, 2, c, True))
     assert rc1 == 0
-    assert res[0][7] == (0, 1501) and res[1][7] == (1501, 3001)
+    assert [r[7] for r in res] == [synthetic.shard_range(3001, r, world) for r in range(world)] and res[-1][7][1] == 3001
     for rank, r, t, iters, evals, calls, rc, _ in res:
         assert rc == 0 and iters == s1.num_iterations and evals == s1.num_evaluations
         assert calls == evals                       # exactly one collective per sweep
         assert np.abs(r - r1).max() < 1e-12 and np.abs(t - t1).max() < 1e-12
-    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])   # ranks stay in lock-step
+    assert all(np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2]) for r in res)   # ranks stay in lock-step
 
 
 def test_shard_range_partitions():
