@@ -335,9 +335,30 @@ int sba_problem_epipolar_moments(sba_problem* p, double* groups);
 int sba_initial_guess_from_moments(const double* groups, int trials, double subset_fraction,
                                    unsigned long long seed, double rot_euler[3], double tran[3],
                                    int* num_candidates);
-/* Both parts.                                                                                                */
+/* Both parts.  SBA_GUESS_SAMPLING=reference in the environment routes this call to sba_problem_initial_guess_reference
+ * (seed is then unused) for problems it supports.                                                            */
 int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction, unsigned long long seed,
                               double rot_euler[3], double tran[3], int* num_candidates);
+
+/* ---- the same initial guess from the REFERENCE'S OWN random subsets (small problems) ------------------------- */
+/* Host-only (no device needed): the match indices the reference's `trials` trials draw for a problem of n matches --
+ * random_array (spherical_bundle_adjuster.hpp:182-211: std::iota + std::random_shuffle on the never-seeded process-wide
+ * rand() stream) constructed once per trial, its first sample_n = (int)(n * subset_fraction) entries used
+ * (spherical_bundle_adjuster.cpp:130-141).  indices: int[trials][sample_n].  Draws (n - 1) values per trial from
+ * std::rand() of THIS process in libstdc++'s order, exactly what the reference's call would consume at this point of the
+ * process -- so call it where the reference calls initial_guess, from that thread.  *sample_n_out receives sample_n
+ * (pass indices = NULL to query it without drawing).                                                            */
+int sba_reference_trial_subsets(int n, int trials, double subset_fraction, int* indices, int* sample_n_out);
+/* Device part: A^T A of the rows kron(left_i, right_i) over each trial's index list.  indices: int[trials][sample_n]
+ * (host), every entry < n; moments: double[trials][45] (host; upper triangle, row-major a <= b).  Single-GPU problems
+ * only (an index list addresses the resident shard).                                                           */
+int sba_problem_epipolar_subset_moments(sba_problem* p, const int* indices, int trials, int sample_n, double* moments);
+/* Both parts + the consensus: what initial_guess (.cpp:118-181) computes, from the subsets the reference itself would
+ * draw.  At most SBA_REFERENCE_SAMPLING_MAX_N matches (the reference's problem sizes; larger problems use the group
+ * sampling of sba_problem_initial_guess), at least 4 (sample_n >= 1).                                          */
+#define SBA_REFERENCE_SAMPLING_MAX_N (1 << 20)
+int sba_problem_initial_guess_reference(sba_problem* p, int trials, double subset_fraction, double rot_euler[3],
+                                        double tran[3], int* num_candidates);
 
 /* ---- batched per-pair solve (BASELINE config C5: many ERP pairs, each its own two-view problem) ------- */
 /* The reference handles one image pair per process run (main/main.cpp:6-34); a batch holds `num_pairs`

@@ -245,3 +245,23 @@ def armijo(phi, cost0, slope0, direction_max_norm=1.0, options: LmOptions | None
     if rc != 0:
         raise RuntimeError("phi callback failed")
     return bool(out[0]), float(out[1]), int(out[2])
+
+
+def reference_trial_subsets(n: int, trials: int = 80, reseed: bool = True) -> np.ndarray:
+    """(trials, int(n * 0.25)) match indices: the reference's random_array (std::iota + the real libstdc++
+    std::random_shuffle on the process-wide rand()) per trial -- oracle/reference_shuffle.cpp.  reseed: srand(1) first, the
+    state of a process that never seeded and has drawn nothing."""
+    m = C.c_int(0)
+    lib().orc_reference_trial_subsets(C.c_int(n), C.c_int(trials), C.c_int(0), None, C.byref(m))
+    out = np.zeros((trials, m.value), dtype=np.int32)
+    lib().orc_reference_trial_subsets(C.c_int(n), C.c_int(trials), C.c_int(1 if reseed else 0), _p(out), C.byref(m))
+    return out
+
+
+def c_srand(seed: int) -> None:
+    """srand() of the C library this process shares with libsba_hip.so (rand() is process state)."""
+    lib().orc_srand(C.c_uint(seed))
+
+
+def c_rand() -> int:
+    return int(lib().orc_rand())

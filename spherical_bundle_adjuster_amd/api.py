@@ -262,6 +262,24 @@ class Problem:
                                                                   _dptr(t), C.byref(n)))
         return e, t, n.value
 
+    def epipolar_subset_moments(self, indices) -> np.ndarray:
+        """indices: (trials, m) int32 match indices -> (trials, 45): A^T A of the kron(left, right) rows of each list."""
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        if idx.ndim != 2:
+            raise ValueError("indices must be (trials, m)")
+        out = np.zeros((idx.shape[0], 45))
+        cabi.check(self._lib, self._lib.sba_problem_epipolar_subset_moments(self._h, idx.ctypes.data_as(C.c_void_p), idx.shape[0],
+                                                                            idx.shape[1], _dptr(out)))
+        return out
+
+    def initial_guess_reference(self, trials: int = 80, subset_fraction: float = 0.25):
+        """The initial guess from the subsets the reference itself would draw (std::random_shuffle on this process's
+        rand() stream, reference .hpp:182-211 / .cpp:130-141).  Returns (euler, tran, number of candidates)."""
+        e, t, n = np.zeros(3), np.zeros(3), C.c_int(0)
+        cabi.check(self._lib, self._lib.sba_problem_initial_guess_reference(self._h, trials, subset_fraction, _dptr(e), _dptr(t),
+                                                                            C.byref(n)))
+        return e, t, n.value
+
     # -- multi-GPU ------------------------------------------------------------------------------------
     def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes) -> None:
         if len(unique_id) != cabi.COMM_ID_BYTES:
@@ -462,6 +480,17 @@ def initial_guess_from_moments(groups, trials: int = 80, subset_fraction: float 
     cabi.check(lib, lib.sba_initial_guess_from_moments(_dptr(g), trials, subset_fraction, seed, _dptr(e), _dptr(t),
                                                        C.byref(n)))
     return e, t, n.value
+
+
+def reference_trial_subsets(n: int, trials: int = 80, subset_fraction: float = 0.25) -> np.ndarray:
+    """Host-only: (trials, int(n * subset_fraction)) match indices the reference's trials draw from THIS process's rand()
+    stream at this point (sba_reference_trial_subsets)."""
+    lib = cabi.load_library()
+    m = C.c_int(0)
+    cabi.check(lib, lib.sba_reference_trial_subsets(n, trials, subset_fraction, None, C.byref(m)))
+    out = np.zeros((trials, m.value), dtype=np.int32)
+    cabi.check(lib, lib.sba_reference_trial_subsets(n, trials, subset_fraction, out.ctypes.data_as(C.c_void_p), C.byref(m)))
+    return out
 
 
 def rccl_available() -> bool:

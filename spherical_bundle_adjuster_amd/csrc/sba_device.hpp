@@ -198,6 +198,11 @@ hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, cons
 hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double* partials, int grid,
                                    double* groups_dev, hipStream_t stream);
 
+// ... the same A^T A per TRIAL over explicit index lists (the reference's own random subsets, .cpp:130-141):
+// indices_dev [trials][m] int32, moments_dev [trials][45].
+hipError_t launch_epipolar_subset_moments(int store, const Planes& pl, size_t n, const int* indices_dev, int trials, int m,
+                                          double* moments_dev, hipStream_t stream);
+
 // pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298)
 hipError_t launch_keypoints_to_sphere(const uint8_t* kp, size_t n, size_t stride_bytes, double im_w,
                                       double im_h, double* out_xyz, hipStream_t stream);

@@ -151,7 +151,59 @@ __global__ __launch_bounds__(1024) void epipolar_fold_kernel(const double* __res
   }
 }
 
+// ---- per-trial A^T A from index lists: the reference's own subsets (initial_guess, .cpp:130-141) ---------------------------
+// Block t handles trial t: its 256 threads stride over the trial's `m` match indices (the first int(n * 0.25) entries of
+// the reference's permutation, built on the host from the process's rand() stream), gather the six coordinates of each
+// match from the planes, accumulate the 36 distinct sums, and fold them in a fixed order (lanes by butterfly, waves in
+// wave order) into moments[t][45].  Meant for the reference's real problem sizes (thousands of matches: the whole pass
+// is a few microseconds of scattered 8-byte loads); large problems use the streaming group pass above.
+template <typename ST>
+__device__ __forceinline__ double load1(const void* plane, size_t i) { return static_cast<double>(reinterpret_cast<const ST*>(plane)[i]); }
+
+template <typename ST>
+__global__ __launch_bounds__(256) void epipolar_subset_moments_kernel(Planes pl, unsigned long long n,
+                                                                      const int* __restrict__ indices, int m,
+                                                                      double* __restrict__ moments) {
+  __shared__ double red[4][kSums];
+  double acc[kSums];
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+  const int* __restrict__ idx = indices + static_cast<size_t>(blockIdx.x) * m;
+  for (int k = threadIdx.x; k < m; k += 256) {
+    const unsigned long long i = static_cast<unsigned long long>(idx[k]);
+    if (i < n)      // a list may only name resident matches (checked on the host too)
+      add_match(load1<ST>(pl.x1[0], i), load1<ST>(pl.x1[1], i), load1<ST>(pl.x1[2], i),
+                load1<ST>(pl.x2[0], i), load1<ST>(pl.x2[1], i), load1<ST>(pl.x2[2], i), acc);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMom) {
+    const int src = kEntryMap.src[threadIdx.x];
+    moments[static_cast<size_t>(blockIdx.x) * kMom + threadIdx.x] = ((red[0][src] + red[1][src]) + red[2][src]) + red[3][src];
+  }
+}
+
 }  // namespace
+
+// indices_dev: [trials][m] int32 match indices (< n); moments_dev: [trials][45].
+hipError_t launch_epipolar_subset_moments(int store, const Planes& pl, size_t n, const int* indices_dev, int trials, int m,
+                                          double* moments_dev, hipStream_t stream) {
+  if (trials <= 0) return hipSuccess;
+  if (store == 0)
+    hipLaunchKernelGGL((epipolar_subset_moments_kernel<double>), dim3(trials), dim3(256), 0, stream, pl,
+                       static_cast<unsigned long long>(n), indices_dev, m, moments_dev);
+  else
+    hipLaunchKernelGGL((epipolar_subset_moments_kernel<float>), dim3(trials), dim3(256), 0, stream, pl,
+                       static_cast<unsigned long long>(n), indices_dev, m, moments_dev);
+  return hipGetLastError();
+}
 
 // groups_dev: [64][45] doubles; partials: [grid][36][64] doubles scratch (sized for 45 by the caller).
 hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double* partials, int grid,

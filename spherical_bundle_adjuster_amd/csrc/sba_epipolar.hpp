@@ -13,10 +13,19 @@
 // A^T A.  Sampling whole groups instead of single matches is the documented deviation (the reference's own
 // sampling cannot be reproduced across C libraries anyway); everything after the null vector follows the reference
 // step by step.  All of it is tiny 9x9 / 3x3 host work.
+//
+// REFERENCE SAMPLING (small problems, round 3): the reference's own subsets CAN be reproduced where it matters -- in the
+// process the reference's main() runs in.  random_array (.hpp:182-211) is std::iota + std::random_shuffle, and
+// libstdc++'s random_shuffle(first, last) is `for i in 1..n-1: swap(a[i], a[std::rand() % (i + 1)])` on the process-wide
+// rand() stream.  reference_trial_subsets() below draws from that very stream in that very order (80 permutations of
+// match indices, the first int(n * 0.25) entries each, .cpp:130-141), so a process that swaps this library in for the
+// Ceres path consumes rand() exactly like the reference and every trial solves from the reference's own matches.  The
+// device then accumulates A^T A per trial from the index lists (sba_epipolar.hip: epipolar_subset_moments_kernel).
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -301,14 +310,21 @@ inline void trial_groups(uint64_t seed, int trial, int count, int* out, const in
 }
 
 // One trial from the summed moments (upper triangle, 45 values): E, its rank-2 projection, R1/R2/t, Euler angles.
+// rows = number of matches behind the moments when it is known and below 9 (0 = at least 9): the reference takes the LAST
+// row of vt from cv::SVDecomp of the rows x 9 matrix A (.cpp:70-73), and with fewer than 9 rows vt has only `rows` rows --
+// its last one is the singular vector of the SMALLEST OF THE `rows` singular values, not a null vector of A; in terms of
+// A^T A: the eigenvector of the rows-th largest eigenvalue.
 inline void trial_from_moments(const double* mom45, float e1[3], float e2[3], float tv[3], bool* v1, bool* v2,
-                               double* E_out /* 9, may be null */) {
+                               double* E_out /* 9, may be null */, int rows = 0) {
   double S[81], w[9], V[81];
   int k = 0;
   for (int a = 0; a < 9; ++a)
     for (int b = a; b < 9; ++b) { S[9 * a + b] = S[9 * b + a] = mom45[k]; ++k; }
   double E[9], lam_min;                                  // eigenvector of the smallest eigenvalue (.cpp:72-74)
-  if (!smallest_eigvec(9, S, E, &lam_min)) {
+  if (rows >= 1 && rows < 9) {
+    jacobi_eigen(9, S, w, V);                            // ascending: the rows-th largest eigenvalue sits at index 9 - rows
+    for (int i = 0; i < 9; ++i) E[i] = V[9 * i + (9 - rows)];
+  } else if (!smallest_eigvec(9, S, E, &lam_min)) {
     jacobi_eigen(9, S, w, V);
     for (int i = 0; i < 9; ++i) E[i] = V[9 * i + 0];
   }
@@ -426,6 +442,51 @@ inline GuessResult initial_guess_from_groups(const double* groups, int trials, d
   for (int trial = 0; trial < trials; ++trial) {
     if (out[trial].v1) res.candidates.push_back(out[trial].c1);   // .cpp:148-157: T_vec is pushed with either rotation
     if (out[trial].v2) res.candidates.push_back(out[trial].c2);
+  }
+  res.num_candidates = static_cast<int>(res.candidates.size());
+  res.picked = consensus_pick(res.candidates);
+  if (res.picked >= 0) {
+    std::memcpy(res.euler, res.candidates[res.picked].euler, sizeof(res.euler));
+    std::memcpy(res.tran, res.candidates[res.picked].tran, sizeof(res.tran));
+  }
+  return res;
+}
+
+// ---- the reference's own subsets (random_array, .hpp:182-211; initial_guess, .cpp:130-141) -------------------------------
+// sample_n = int(match_size * 0.25) like `int sample_n = match_size*0.25;` (.cpp:133).
+inline int reference_sample_size(int n, double fraction = 0.25) { return static_cast<int>(n * fraction); }
+
+// out[trial * sample_n + k] = the k-th index trial `trial` draws.  Consumes (n - 1) values of the PROCESS-WIDE std::rand()
+// stream per trial, in the order libstdc++'s std::random_shuffle(first, last) does:
+//     for (i = first + 1; i != last; ++i) { j = first + std::rand() % ((i - first) + 1); if (i != j) iter_swap(i, j); }
+// -- a fresh permutation of 0..n-1 per trial (random_array's constructor), its first sample_n entries used.  Not
+// thread-safe by nature (rand() is process state): call it from the thread the reference would call initial_guess on.
+inline void reference_trial_subsets(int n, int trials, double fraction, int* out) {
+  const int sample_n = reference_sample_size(n, fraction);
+  std::vector<int> perm(static_cast<size_t>(std::max(n, 0)));
+  for (int trial = 0; trial < trials; ++trial) {
+    for (int i = 0; i < n; ++i) perm[i] = i;                                  // std::iota
+    for (int i = 1; i < n; ++i) {                                             // std::random_shuffle, libstdc++
+      const int j = std::rand() % (i + 1);
+      if (i != j) std::swap(perm[i], perm[j]);
+    }
+    for (int k = 0; k < sample_n; ++k) out[static_cast<size_t>(trial) * sample_n + k] = perm[k];
+  }
+}
+
+// The trials' own A^T A (moments: [trials][45], each over `rows` matches) -> candidates -> consensus, as
+// initial_guess_from_groups does for group sums.
+inline GuessResult initial_guess_from_trial_moments(const double* moments, int trials, int rows) {
+  GuessResult res;
+  for (int trial = 0; trial < trials; ++trial) {
+    Candidate c1{}, c2{};
+    bool v1 = false, v2 = false;
+    float tv[3];
+    trial_from_moments(moments + static_cast<size_t>(trial) * kMom, c1.euler, c2.euler, tv, &v1, &v2, nullptr, rows);
+    for (int i = 0; i < 3; ++i) c1.tran[i] = c2.tran[i] = tv[i];
+    c1.trial = c2.trial = trial; c1.which = 1; c2.which = 2;
+    if (v1) res.candidates.push_back(c1);          // .cpp:148-157
+    if (v2) res.candidates.push_back(c2);
   }
   res.num_candidates = static_cast<int>(res.candidates.size());
   res.picked = consensus_pick(res.candidates);

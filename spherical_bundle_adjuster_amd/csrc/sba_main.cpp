@@ -4,10 +4,12 @@
 // integrator.  Without OpenCV -- this image -- <L>/<R> are files of matched
 // cv::KeyPoint records (28 bytes each, same count, match i = record i), preceded by a 16-byte
 // header {int32 count, int32 im_width, int32 im_height, int32 reserved}.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 #include "spherical_bundle_adjuster.hpp"
 
@@ -31,7 +33,7 @@ int main(int argc, char** argv) {
   }
   spherical_bundle_adjuster sph_ba(atof(argv[3]), atof(argv[4]), atof(argv[5]), atof(argv[6]), atof(argv[7]),
                                    atof(argv[8]), atof(argv[9]));
-  sph_ba.set_omp(1);
+  sph_ba.set_omp(static_cast<int>(std::max(1u, std::thread::hardware_concurrency())));   // omp_get_num_procs(), main/main.cpp:31
   // SBA_INITIAL_GUESS=0: start from the expected values on the command line instead of the 8-point consensus
   if (const char* env = std::getenv("SBA_INITIAL_GUESS")) sph_ba.set_initial_guess(env[0] != '0');
   std::vector<cv::KeyPoint> left_key, right_key;

@@ -204,8 +204,76 @@ int sba_initial_guess_from_moments(const double* groups, int trials, double subs
   return SBA_OK;
 }
 
+int sba_reference_trial_subsets(int n, int trials, double subset_fraction, int* indices, int* sample_n_out) {
+  if (n < 0 || trials < 0 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "bad n / trials / subset_fraction");
+  if (sample_n_out) *sample_n_out = sba::epi::reference_sample_size(n, subset_fraction);
+  if (indices) sba::epi::reference_trial_subsets(n, trials, subset_fraction, indices);
+  return SBA_OK;
+}
+
+int sba_problem_epipolar_subset_moments(sba_problem* p, const int* indices, int trials, int sample_n, double* moments) {
+  if (!p || !moments || (trials > 0 && sample_n > 0 && !indices)) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
+  if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  if (trials < 0 || sample_n < 0) return sba::set_error(SBA_ERR_INVALID_ARG, "bad trials / sample_n");
+  if (sba::shim::is_collective(p))
+    return sba::set_error(SBA_ERR_UNSUPPORTED, "index lists address one resident shard: detach the transport (sharded problems use "
+                                               "the group sampling of sba_problem_initial_guess)");
+  const size_t count = static_cast<size_t>(trials) * static_cast<size_t>(sample_n);
+  for (size_t k = 0; k < count; ++k)
+    if (indices[k] < 0 || static_cast<size_t>(indices[k]) >= p->n)
+      return sba::set_error(SBA_ERR_INVALID_ARG, "index %d of list entry %zu is outside the %zu resident matches", indices[k], k, p->n);
+  const size_t msz = static_cast<size_t>(trials) * sba::epi::kMom;
+  if (trials == 0) return SBA_OK;
+  if (sample_n == 0) { std::memset(moments, 0, msz * sizeof(double)); return SBA_OK; }
+  SBA_TRY_HIP(hipSetDevice(p->device));
+  sba::DeviceBuffer idx_dev(&p->poisoned), mom_dev(&p->poisoned);
+  SBA_TRY_HIP(idx_dev.alloc(count * sizeof(int)));
+  SBA_TRY_HIP(mom_dev.alloc(msz * sizeof(double)));
+  SBA_TRY_HIP(hipMemcpyAsync(idx_dev.ptr, indices, count * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+  pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+  SBA_TRY_HIP(sba::launch_epipolar_subset_moments(p->store, pl, p->n, idx_dev.as<int>(), trials, sample_n, mom_dev.as<double>(),
+                                                  p->stream));
+  SBA_TRY_HIP(hipMemcpyAsync(moments, mom_dev.ptr, msz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  { const int _rc = sba::stream_wait(p->stream, "subset moments", &p->poisoned); if (_rc) return _rc; }
+  return SBA_OK;
+}
+
+int sba_problem_initial_guess_reference(sba_problem* p, int trials, double subset_fraction, double rot_euler[3],
+                                        double tran[3], int* num_candidates) {
+  if (!p || !rot_euler || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(p);
+  if (!p->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no correspondences uploaded");
+  if (trials < 1 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "bad trials / subset_fraction");
+  if (p->n > static_cast<size_t>(SBA_REFERENCE_SAMPLING_MAX_N))
+    return sba::set_error(SBA_ERR_UNSUPPORTED, "reference sampling shuffles all %zu match indices per trial: meant for at most %d "
+                                               "matches (use sba_problem_initial_guess)", p->n, SBA_REFERENCE_SAMPLING_MAX_N);
+  const int n = static_cast<int>(p->n);
+  const int sample_n = sba::epi::reference_sample_size(n, subset_fraction);
+  if (sample_n < 1)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "%d matches give an empty subset (the reference's cv::SVDecomp of a 0 x 9 matrix fails too)", n);
+  std::vector<int> indices(static_cast<size_t>(trials) * sample_n);
+  sba::epi::reference_trial_subsets(n, trials, subset_fraction, indices.data());
+  std::vector<double> moments(static_cast<size_t>(trials) * sba::epi::kMom);
+  const int rc = sba_problem_epipolar_subset_moments(p, indices.data(), trials, sample_n, moments.data());
+  if (rc) return rc;
+  const sba::epi::GuessResult r = sba::epi::initial_guess_from_trial_moments(moments.data(), trials, sample_n);
+  if (num_candidates) *num_candidates = r.num_candidates;
+  if (r.picked < 0) return sba::set_error(SBA_ERR_NUMERIC, "no valid rotation candidate (all Euler angles >= 1.57)");
+  for (int i = 0; i < 3; ++i) { rot_euler[i] = r.euler[i]; tran[i] = r.tran[i]; }
+  return SBA_OK;
+}
+
 int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction, unsigned long long seed,
                               double rot_euler[3], double tran[3], int* num_candidates) {
+  if (const char* env = std::getenv("SBA_GUESS_SAMPLING"))
+    if (std::strcmp(env, "reference") == 0 && p && !sba::shim::is_collective(p) && p->n >= 4 &&
+        p->n <= static_cast<size_t>(SBA_REFERENCE_SAMPLING_MAX_N))
+      return sba_problem_initial_guess_reference(p, trials, subset_fraction, rot_euler, tran, num_candidates);
   std::vector<double> groups(static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom);
   const int rc = sba_problem_epipolar_moments(p, groups.data());
   if (rc) return rc;

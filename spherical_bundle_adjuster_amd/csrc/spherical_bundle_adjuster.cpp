@@ -5,6 +5,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -81,7 +83,16 @@ int spherical_bundle_adjuster::do_bundle_adjustment_from_matches(const std::vect
     std::cout << "E matrix estimation with SVD" << std::endl;                           // .cpp:127
     double euler[3], tvec[3];
     int candidates = 0;
-    rc = sba_problem_initial_guess(problem, 80, 0.25, guess_seed, euler, tvec, &candidates);   // .cpp:130-133
+    guess_sampling_t how = guess_sampling;
+    if (const char* env = std::getenv("SBA_GUESS_SAMPLING")) {
+      if (std::strcmp(env, "groups") == 0) how = GUESS_GROUPS;
+      else if (std::strcmp(env, "reference") == 0) how = GUESS_REFERENCE;
+    }
+    if (how == GUESS_AUTO) how = (match_size >= 4 && match_size <= kReferenceSamplingMaxN) ? GUESS_REFERENCE : GUESS_GROUPS;
+    if (how == GUESS_REFERENCE)   // 80 x random_array(match_size), int(match_size * 0.25) matches each: .cpp:130-141
+      rc = sba_problem_initial_guess_reference(problem, 80, 0.25, euler, tvec, &candidates);
+    else
+      rc = sba_problem_initial_guess(problem, 80, 0.25, guess_seed, euler, tvec, &candidates);
     if (rc) return rc;
     for (int i = 0; i < 3; ++i) { init_rot[i] = -euler[i]; init_tran[i] = tvec[i]; }     // .cpp:330-331
     res.guess_candidates = candidates;

@@ -57,6 +57,14 @@ class spherical_bundle_adjuster {
   void set_depth_log_name(const std::string& name) { depth_log_name = name; }
   // true (default, like the reference): start from the 8-point consensus; false: from the expected values.
   void set_initial_guess(bool on, unsigned long long seed = 0) { use_initial_guess = on; guess_seed = seed; }
+  // Which subsets the 80 trials of the initial guess solve from.  GUESS_AUTO (default): up to kReferenceSamplingMaxN
+  // matches -- every size the reference is run at -- the reference's OWN subsets (random_array: std::random_shuffle on the
+  // process's rand() stream, .hpp:182-211, drawn where the reference draws them, so this process consumes rand() exactly
+  // as the reference does and the trials see the reference's matches); above that, seeded groups of matches
+  // (one streaming device pass instead of 80 shuffles of all indices).  SBA_GUESS_SAMPLING=groups|reference overrides.
+  enum guess_sampling_t { GUESS_AUTO = 0, GUESS_GROUPS = 1, GUESS_REFERENCE = 2 };
+  static constexpr int kReferenceSamplingMaxN = 65536;
+  void set_guess_sampling(guess_sampling_t s) { guess_sampling = s; }
   // Everything after the matcher: pixel -> sphere, initial values, three-stage solve, log row.
   // Returns 0 or a negative SBA_ERR_* (message via sba_last_error()).
   int do_bundle_adjustment_from_matches(const std::vector<cv::KeyPoint>& left_key,
@@ -86,6 +94,7 @@ class spherical_bundle_adjuster {
   matcher_fn matcher;
   bool use_initial_guess = true;
   unsigned long long guess_seed = 0;
+  guess_sampling_t guess_sampling = GUESS_AUTO;
   const void* resident_left = nullptr;   // coordinates currently resident in `problem`
   int resident_n = -1;
   sba_problem* problem = nullptr;

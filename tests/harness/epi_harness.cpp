@@ -16,4 +16,17 @@ void harness_trial(const double* mom45, float* e1, float* e2, float* tv, int* v1
   trial_from_moments(mom45, e1, e2, tv, &a, &b, E);
   *v1 = a; *v2 = b;
 }
+void harness_trial_rows(const double* mom45, int rows, float* e1, float* e2, float* tv, int* v1, int* v2, double* E) {
+  bool a, b;
+  trial_from_moments(mom45, e1, e2, tv, &a, &b, E, rows);
+  *v1 = a; *v2 = b;
+}
+// moments [trials][45] over `rows` matches each -> R_vec_out, T_vec_out, candidates (the host half of
+// sba_problem_initial_guess_reference)
+int harness_guess_from_trial_moments(const double* moments, int trials, int rows, float* euler, float* tran, int* ncand) {
+  const GuessResult r = initial_guess_from_trial_moments(moments, trials, rows);
+  *ncand = r.num_candidates;
+  for (int i = 0; i < 3; ++i) { euler[i] = r.euler[i]; tran[i] = r.tran[i]; }
+  return r.picked;
+}
 }

@@ -104,6 +104,7 @@ hipError_t launch_depth_step(int, const Planes&, const double*, const double*, d
   publish(host, 24, seq); return hipSuccess;
 }
 hipError_t launch_epipolar_moments(int, const Planes&, size_t, double*, int, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_epipolar_subset_moments(int, const Planes&, size_t, const int*, int, int, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_keypoints_to_sphere(const uint8_t*, size_t, size_t, double, double, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_keypoints_to_planes(const uint8_t*, const uint8_t*, size_t, size_t, double, double, void* const*, int, hipStream_t) { return hipSuccess; }
 }  // namespace sba

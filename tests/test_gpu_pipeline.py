@@ -96,7 +96,10 @@ def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
     x1 = oracle.keypoints_to_sphere(kl, W, H); x2 = oracle.keypoints_to_sphere(kr, W, H)
     with api.Problem(0) as p:
         p.upload(x1, x2)
-        e, t, ncand = p.initial_guess(80, 0.25, 0)
+        # the CLI is a fresh process: never-seeded rand(), nothing drawn before initial_guess -- the reference's own
+        # subsets (the mirror class's default up to 65 536 matches).  Same state here: srand(1), then the same draws.
+        oracle.c_srand(1)
+        e, t, ncand = p.initial_guess_reference(80, 0.25)
     assert ncand > 40
     rot0, tran0 = -e, t
     d, _, rc = oracle.depth_solve(x1, x2, rot0, tran0, np.full((n, 2), exp_d))

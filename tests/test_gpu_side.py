@@ -118,6 +118,48 @@ def test_epipolar_moments_vs_numpy(n, store):
             assert np.array_equal(e, e2) and np.array_equal(t, t2) and ncand == n2
 
 
+@pytest.mark.parametrize("n,store", [(20, api.STORE_F64), (40, api.STORE_F64), (2048, api.STORE_F64), (2048, api.STORE_F32),
+                                     (50001, api.STORE_F64)])
+def test_initial_guess_from_the_reference_subsets(oracle, n, store, monkeypatch):
+    """SURVEY 8 f-1 with the reference's OWN sampling (VERDICT r2 item 7): 80 x random_array(n) -- std::iota +
+    std::random_shuffle on the process's rand() stream (reference .hpp:182-211), the first int(n * 0.25) entries each
+    (.cpp:130-141).  The oracle draws the lists with the real libstdc++ std::random_shuffle; the product must (a) draw
+    the same lists from the same rand() state, (b) accumulate each list's A^T A on the device (vs numpy, 1e-12), (c) reach
+    the consensus R_vec_out / T_vec_out of the reference recipe in numpy (explicit A + LAPACK SVD) on those lists --
+    at the float32 resolution the reference keeps them in (cv::Vec3f).  BASELINE config C1 is n ~ 2 k."""
+    from test_initial_guess_cpu import _recipe_on_subsets, subset_moments
+    c = synthetic.full_rt(n, seed=900 + n, sigma=2e-4, outlier_fraction=0.0)
+    x1, x2 = (c.x1, c.x2) if store == api.STORE_F64 else (c.x1.astype(np.float32).astype(np.float64),
+                                                          c.x2.astype(np.float32).astype(np.float64))
+    subsets = oracle.reference_trial_subsets(n, 80, reseed=True)
+    oracle.c_srand(1)
+    assert np.array_equal(api.reference_trial_subsets(n, 80, 0.25), subsets)
+    e_ref, t_ref, nc_ref = _recipe_on_subsets(x1, x2, subsets)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, store=store)
+        mom = p.epipolar_subset_moments(subsets)
+        ref = subset_moments(x1, x2, subsets)
+        assert np.abs(mom - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.array_equal(mom, p.epipolar_subset_moments(subsets))              # fixed fold order
+        oracle.c_srand(1)
+        e, t, nc = p.initial_guess_reference(80, 0.25)
+        after = oracle.c_rand()
+        # SBA_GUESS_SAMPLING=reference routes the seeded entry point to the same path
+        monkeypatch.setenv("SBA_GUESS_SAMPLING", "reference")
+        oracle.c_srand(1)
+        e2, t2, nc2 = p.initial_guess(80, 0.25, 12345)
+        monkeypatch.delenv("SBA_GUESS_SAMPLING")
+        assert np.array_equal(e, e2) and np.array_equal(t, t2) and nc == nc2
+        with pytest.raises(api.SbaError):
+            p.epipolar_subset_moments(np.full((2, 3), n, dtype=np.int32))            # index out of range
+    oracle.reference_trial_subsets(n, 80, reseed=True)
+    assert after == oracle.c_rand()                                                  # consumed exactly the reference's draws
+    loose = 1e-4 if n == 20 else 0.0           # 5 rows per trial: E is the 5th singular vector of a 5 x 9 matrix, ill-conditioned
+    assert nc == nc_ref
+    assert np.abs(e - e_ref).max() < 2e-6 * max(1.0, np.abs(e_ref).max()) + loose, (e, e_ref)
+    assert min(np.abs(t - t_ref).max(), np.abs(t + t_ref).max()) < 1e-5 + 10 * loose
+
+
 def test_set_depths(oracle):
     c = synthetic.full_rt(3000, seed=77)
     with api.Problem(0) as p:

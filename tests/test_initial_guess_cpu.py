@@ -245,3 +245,91 @@ def test_trial_subsets_with_few_matches_hold_at_least_eight():
     h.harness_trial_groups(C.c_ulonglong(5), C.c_int(3), C.c_int(16), _p(a))
     h.harness_trial_groups_from(C.c_ulonglong(5), C.c_int(3), C.c_int(16), _p(b), _p(full), C.c_int(64))
     assert np.array_equal(a, b)
+
+
+# ---- the reference's own subsets (random_array / std::random_shuffle on the process's rand() stream) --------------------------
+def test_glibc_rand_stream_is_the_one_the_reference_runs_on(oracle):
+    """Known answers of glibc's never-seeded rand() (= srand(1), C standard 7.22.2.2): what `random_array` consumes in a
+    reference process that has drawn nothing yet.  If this fails the C library is not the reference's and the subsets
+    below are still self-consistent (product == std::random_shuffle) but no longer the reference's."""
+    oracle.c_srand(1)
+    assert [oracle.c_rand() for _ in range(5)] == [1804289383, 846930886, 1681692777, 1714636915, 1957747793]
+
+
+@pytest.mark.parametrize("n", [4, 5, 40, 333, 2048])
+def test_reference_subsets_equal_libstdcxx_random_shuffle(oracle, n):
+    """Product (hand-written loop on std::rand(), csrc/sba_epipolar.hpp) == the oracle's call of the REAL libstdc++
+    std::random_shuffle -- the function the reference itself calls (spherical_bundle_adjuster.hpp:209) -- element for
+    element over all 80 trials, from the same rand() state; and both consume the same number of draws."""
+    ref = oracle.reference_trial_subsets(n, 80, reseed=True)
+    after_ref = oracle.c_rand()
+    oracle.c_srand(1)
+    got = api.reference_trial_subsets(n, 80, 0.25)
+    after_got = oracle.c_rand()
+    assert ref.shape == got.shape == (80, int(n * 0.25)) and np.array_equal(ref, got) and after_ref == after_got
+    for row in got:                                   # each a prefix of a permutation of 0..n-1
+        assert len(set(row.tolist())) == len(row) and (row >= 0).all() and (row < n).all()
+    if n >= 40:
+        assert len({tuple(r) for r in got.tolist()}) == 80        # a FRESH permutation per trial
+    # mid-stream (a matcher -- FLANN's kd-trees call rand() -- ran first): still the same lists from the same state
+    oracle.c_srand(1)
+    burn = [oracle.c_rand() for _ in range(1234)]
+    ref2 = oracle.reference_trial_subsets(n, 3, reseed=False)
+    oracle.c_srand(1)
+    assert [oracle.c_rand() for _ in range(1234)] == burn
+    assert np.array_equal(ref2, api.reference_trial_subsets(n, 3, 0.25)) and (n < 40 or not np.array_equal(ref2, ref[:3]))
+
+
+def _recipe_on_subsets(x1, x2, subsets):
+    """The reference's initial_guess (.cpp:118-181) in numpy on GIVEN subsets: explicit A, LAPACK SVD, last row of vt (for
+    fewer than 9 rows that is row m - 1 of the economy vt, as cv::SVDecomp returns it), rank 2, R1 / R2, float32 Euler
+    angles, validity, 20-80 % trimmed-mean consensus."""
+    A = (x1[:, :, None] * x2[:, None, :]).reshape(len(x1), 9)
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    cands, tvecs = [], []
+    for idx in subsets:
+        vt = np.linalg.svd(A[idx], full_matrices=False)[2]
+        E = vt[-1].reshape(3, 3)
+        U, s, Vt = np.linalg.svd(E)
+        U, s, Vt = np.linalg.svd(U @ np.diag([s[0], s[1], 0.0]) @ Vt)
+        if np.linalg.det(U) < 0: U = -U
+        if np.linalg.det(Vt) < 0: Vt = -Vt
+        for R in (U @ W @ Vt, U @ W.T @ Vt):
+            e = euler_of(R).astype(np.float32)
+            if np.abs(e).max() < 1.57:
+                cands.append(e); tvecs.append(U[:, 2])
+    c = np.array(cands, dtype=np.float32)
+    if len(c) == 0:
+        return None, None, 0
+    d = np.sort(np.linalg.norm((c[:, None, :] - c[None, :, :]).astype(np.float64), axis=2), axis=1)
+    lo, hi = int(len(c) * 0.2), int(len(c) * 0.8)
+    pick = int(np.argmin(d[:, lo:hi].mean(axis=1)))
+    return c[pick], tvecs[pick], len(c)
+
+
+def subset_moments(x1, x2, subsets):
+    A = (x1[:, :, None] * x2[:, None, :]).reshape(len(x1), 9)
+    iu = np.triu_indices(9)
+    return np.stack([(A[idx].T @ A[idx])[iu] for idx in subsets])
+
+
+@pytest.mark.parametrize("n", [20, 40, 2048])
+def test_guess_from_the_reference_subsets_equals_the_numpy_recipe(oracle, n):
+    """Host half of sba_problem_initial_guess_reference (per-trial A^T A -> eigenvector -> rank 2 -> R1 / R2 -> consensus)
+    against the reference recipe in numpy (explicit A, LAPACK SVD) on the SAME subsets -- the ones libstdc++'s
+    std::random_shuffle draws.  n = 20: 5 rows per trial, fewer than 9 -- the last row of cv::SVDecomp's vt is then the
+    5th singular vector, not a null vector of A.  Euler angles are float32 in the reference (cv::Vec3f)."""
+    c = synthetic.full_rt(n, seed=900 + n, sigma=2e-4, outlier_fraction=0.0)
+    subsets = oracle.reference_trial_subsets(n, 80, reseed=True)
+    rows = subsets.shape[1]
+    mom = np.ascontiguousarray(subset_moments(c.x1, c.x2, subsets))
+    e, t, nc = np.zeros(3, np.float32), np.zeros(3, np.float32), C.c_int(0)
+    h = harness()
+    h.harness_guess_from_trial_moments.restype = C.c_int
+    picked = h.harness_guess_from_trial_moments(_p(mom), C.c_int(80), C.c_int(rows), _p(e), _p(t), C.byref(nc))
+    e_ref, t_ref, nc_ref = _recipe_on_subsets(c.x1, c.x2, subsets)
+    assert picked >= 0 and nc.value == nc_ref, (nc.value, nc_ref)
+    assert np.abs(e - e_ref).max() < 2e-6 * max(1.0, np.abs(e_ref).max()) + (1e-4 if n == 20 else 0.0), (e, e_ref)
+    assert min(np.abs(t - t_ref).max(), np.abs(t + t_ref).max()) < 1e-5 + (1e-3 if n == 20 else 0.0)
+    if n >= 2048:        # enough matches per trial for a usable guess: near the true rotation (left^T E right = 0 => R^T)
+        assert np.abs(e - euler_of(synthetic.rodrigues(c.rot_true).T)).max() < 0.05
