@@ -71,11 +71,11 @@ struct DepthRegs {
   }
 };
 
-// OCC = resident 256-thread blocks per CU the register allocation is held to (__launch_bounds__' second argument is waves
-// per SIMD = blocks per CU for 256-thread blocks): 2 lets the allocator keep both matches' temporaries and the whole
-// double buffer in registers (187 VGPRs); 3 / 4 trade registers for resident waves (SBA_DEPTH_OCC, profiles/r03_depth_tune.md).
-template <typename ST, int OCC>
-__global__ __launch_bounds__(256, OCC) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
+// Two resident 256-thread blocks per CU: 187 VGPRs hold both matches' temporaries and the whole register double buffer.
+// Holding the allocation to 3 / 4 blocks per CU (168 / 128 VGPRs, 84 / 244 B of scratch) was measured and is far worse:
+// 231-279 / 499-517 us per pass against 185 us (profiles/r03_depth_tune.log) -- the spills sit in the hot loop.
+template <typename ST>
+__global__ __launch_bounds__(256, 2) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
                                                         const double* __restrict__ d2,
                                                         double* __restrict__ c1, double* __restrict__ c2,
                                                         double* __restrict__ sc1, double* __restrict__ sc2,
@@ -223,22 +223,18 @@ __global__ __launch_bounds__(64 * DEPTH_OUT_COUNT) void depth_finalize_kernel(co
 }  // namespace
 
 typedef void (*DepthFn)(Planes, const double*, const double*, double*, double*, double*, double*, DepthParams, double*);
-template <typename ST>
-DepthFn depth_pick_occ(int occ) {
-  return occ >= 4 ? depth_step_kernel<ST, 4> : (occ == 3 ? depth_step_kernel<ST, 3> : depth_step_kernel<ST, 2>);
-}
-DepthFn depth_pick(int store, int occ) { return store == 0 ? depth_pick_occ<double>(occ) : depth_pick_occ<float>(occ); }
+DepthFn depth_pick(int store) { return store == 0 ? depth_step_kernel<double> : depth_step_kernel<float>; }
 
-hipError_t depth_blocks_per_cu(int store, int occ, int* blocks) {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(depth_pick(store, occ)), 256, 0);
+hipError_t depth_blocks_per_cu(int store, int* blocks) {
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(depth_pick(store)), 256, 0);
 }
 
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2,
-                             const DepthParams& prm, double* partials, int grid, int occ, double* out, double* host_out,
+                             const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream) {
   if (grid > 0) {
-    hipLaunchKernelGGL(depth_pick(store, occ), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1, sc2, prm, partials);
+    hipLaunchKernelGGL(depth_pick(store), dim3(grid), dim3(256), 0, stream, pl, d1, d2, c1, c2, sc1, sc2, prm, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

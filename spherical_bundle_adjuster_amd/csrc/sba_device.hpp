@@ -186,11 +186,10 @@ struct DepthParams {
 // gather_slot >= 0 (sharded problem): `out` is a 24-double pack for a SUM all-reduce, the sums in [0..6], this rank's
 // two maxima in [8 + gather_slot] and [16 + gather_slot] (gather_slot < 8), zeros elsewhere; nothing is published to
 // the host.  Candidates go to (c1, c2); (sc*) hold the per-parameter Jacobi scaling.  partials: [grid][16].
-// resident 256-thread blocks per CU of depth_step_kernel's variant compiled for `occ` (2, 3 or 4) blocks per CU
-hipError_t depth_blocks_per_cu(int store, int occ, int* blocks);
+hipError_t depth_blocks_per_cu(int store, int* blocks);   // resident 256-thread blocks per CU of depth_step_kernel
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,
                              double* c2, double* sc1, double* sc2,
-                             const DepthParams& prm, double* partials, int grid, int occ, double* out, double* host_out,
+                             const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream);
 
 // 8-point initial guess, device part (.cpp:53-68): A^T A of the kron(left, right) rows for 64 interleaved groups.

@@ -25,7 +25,7 @@ struct sba_problem {
                                // waves only add rows to fold and finish-time spread, profiles/r01_tune_caps.log)
   int kind = SBA_KERNEL_FACTORED;
   int occ_cache[3][2][2][2][2];  // resident blocks/CU per [mode][depth][store][kind][loss], 0 = unknown
-  int depth_occ[2][3] = {{0, 0, 0}, {0, 0, 0}};   // same for depth_step_kernel per [store][register variant]
+  int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
   double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
   size_t epi_scratch_elems = 0;
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep

@@ -49,11 +49,9 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   double* work = work_buf.as<double>();
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems;
   // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
-  int variant = 2;      // register budget the kernel variant is compiled for, in resident blocks per CU
-  if (const char* env = std::getenv("SBA_DEPTH_OCC")) { const int v = std::atoi(env); if (v >= 2 && v <= 4) variant = v; }
-  int& occ = p->depth_occ[p->store][variant - 2];
+  int& occ = p->depth_occ[p->store];
   if (occ == 0) {
-    SBA_TRY_HIP(sba::depth_blocks_per_cu(p->store, variant, &occ));
+    SBA_TRY_HIP(sba::depth_blocks_per_cu(p->store, &occ));
     occ = std::max(1, occ);
   }
   int cap = 8;
@@ -89,7 +87,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     prm.radius = rq.radius; prm.inv_radius = 1.0 / rq.radius; prm.alpha = rq.alpha;
     prm.first_iteration = rq.first ? 1 : 0; prm.reuse_diagonal = rq.keep_diagonal ? 1 : 0;
     if (collective) {
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid, variant,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
                                          p->pack_dev, nullptr, 0, p->shard_rank, p->stream));
       int rc = allreduce_pack(p);
       if (rc) return rc;
@@ -107,13 +105,13 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     if (p->publish) {
       // the finalize kernel publishes the results itself; the host polls the sequence word (see fetch_pack_raw)
       const unsigned long long seq = ++p->seq;
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid, variant,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
                                          out_dev, p->pack_host_dev, seq, -1, p->stream));
       const int rc = sba::wait_for_sequence(reinterpret_cast<volatile unsigned long long*>(p->pack_host + 24), seq,
                                             p->stream, "d-only pass", &p->poisoned);
       if (rc) return rc;
     } else {
-      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid, variant,
+      SBA_TRY_HIP(sba::launch_depth_step(p->store, pl, cur1, cur2, c1, c2, sc1, sc2, prm, partials, grid,
                                          out_dev, nullptr, 0, -1, p->stream));
       SBA_TRY_HIP(hipMemcpyAsync(p->pack_host, out_dev, sizeof(out), hipMemcpyDeviceToHost, p->stream));
       { const int _rc = sba::stream_wait(p->stream, "stream synchronisation", &p->poisoned); if (_rc) return _rc; }

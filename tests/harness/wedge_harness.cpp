@@ -67,7 +67,7 @@ namespace sba {
 int points_per_lane(int store) { return store == 0 ? 2 : 4; }
 hipError_t sweep_blocks_per_cu(int, int, int, int, bool, int* b) { *b = 2; return hipSuccess; }
 hipError_t batch_blocks_per_cu(int, int, int, int, bool, int* b) { *b = 2; return hipSuccess; }
-hipError_t depth_blocks_per_cu(int, int, int* b) { *b = 2; return hipSuccess; }
+hipError_t depth_blocks_per_cu(int, int* b) { *b = 2; return hipSuccess; }
 hipError_t launch_sweep(int, int, int, int, const Planes&, const SweepParams&, const SweepOut& o, int, hipStream_t) {
   publish(o.pack_host, 24, o.seq); return hipSuccess;
 }
@@ -100,7 +100,7 @@ hipError_t launch_aos_to_planes(const double*, size_t, size_t, void*, void*, voi
 hipError_t launch_d12_to_planes(const double*, size_t, size_t, double*, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_planes_to_d12(const double*, const double*, size_t, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_depth_step(int, const Planes&, const double*, const double*, double*, double*, double*, double*, const DepthParams&, double*,
-                             int, int, double*, double* host, unsigned long long seq, int, hipStream_t) {
+                             int, double*, double* host, unsigned long long seq, int, hipStream_t) {
   publish(host, 24, seq); return hipSuccess;
 }
 hipError_t launch_epipolar_moments(int, const Planes&, size_t, double*, int, double*, hipStream_t) { return hipSuccess; }
