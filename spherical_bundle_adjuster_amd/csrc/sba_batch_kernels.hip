@@ -4,6 +4,7 @@
 #include <new>
 
 #include "sba_lm.hpp"
+#include "sba_resident.hpp"
 #include "sba_sweep_core.hpp"
 
 namespace sba {
@@ -407,6 +408,54 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
   }
 }
 
+// ---- resident evaluator of ONE small problem (sba_resident.hpp) ---------------------------------------------------------
+// One block stays resident for a whole solve stage: per trip wave 0 publishes the previous sweep's sums to the host and
+// waits (bounded in time) for the next command in the mapped record; the block then sweeps all matches with the
+// commanded state -- the same block_sweep_fold the one-launch batch kernels use, same fold order -- and loops.  The loop
+// has the shape of batch_lm_kernel's: the one divergent (wave-0) region of a trip sits between two barriers of that trip,
+// the trip count is bounded by a counter every thread keeps, the exit decision is read from LDS after a barrier.
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void resident_sweep_kernel(Planes pl, unsigned long long n_resident,
+                                                               const ResidentRecord* __restrict__ rec,
+                                                               double* __restrict__ host_pack,
+                                                               unsigned long long first_cmd_seq,
+                                                               unsigned long long first_pack_seq,
+                                                               unsigned long long idle_ticks) {
+  __shared__ double wave_out[(kBlock / 64) * 24];
+  __shared__ double raw_s[24];
+  __shared__ double cmd_s[kResidentPayload];
+  __shared__ int end_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) end_s = 0;
+  for (int trip = 0; trip < kResidentMaxTrips; ++trip) {
+    __syncthreads();                                   // B0: the previous trip's sums are complete
+    if (tid < 64) {                                    // wave 0: answer, then wait for the next command
+      if (trip > 0) resident_publish(host_pack, raw_s, 24, first_pack_seq + static_cast<unsigned long long>(trip - 1));
+      int end = 0;
+      resident_wait_command(rec, first_cmd_seq + static_cast<unsigned long long>(trip), idle_ticks, cmd_s, &end);
+      if (tid == 0 && end) end_s = end;
+    }
+    __syncthreads();                                   // B1: command (or the end reason) visible to the block
+    if (end_s) break;
+    const int op = static_cast<int>(cmd_s[0]);
+    if (op != RESIDENT_OP_SWEEP) {
+      if (tid == 0) end_s = op == RESIDENT_OP_QUIT ? RESIDENT_END_QUIT : RESIDENT_END_BAD_OP;
+      break;
+    }
+    SweepParams prm;
+#pragma unroll
+    for (int k = 0; k < 42; ++k) reinterpret_cast<double*>(&prm)[k] = cmd_s[1 + k];
+    unsigned long long n_cmd;
+    const double nd = cmd_s[43];
+    __builtin_memcpy(&n_cmd, &nd, sizeof(n_cmd));
+    const size_t n = n_cmd < n_resident ? n_cmd : n_resident;      // never past the resident matches, whatever the record says
+    prm.n = n;
+    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, 0, n, prm, wave_out, raw_s);
+  }
+  __syncthreads();
+  if (tid < 64) resident_publish_end(host_pack, end_s ? end_s : RESIDENT_END_TRIPS);
+}
+
 // ---- batch kernel table (same template axes as the single-problem sweep) ---------------------------------------
 typedef void (*BatchFn)(Planes, const SweepParams*, const PairDesc*, int, double*);
 template <int MODE, int DEPTH, typename ST, int KIND>
@@ -461,6 +510,33 @@ BatchLmFn lpick(int mode, int depth, int store, int kind, bool loss) {
   return nullptr;
 }
 
+typedef void (*ResidentFn)(Planes, unsigned long long, const ResidentRecord*, double*, unsigned long long, unsigned long long,
+                           unsigned long long);
+template <int MODE, int DEPTH, typename ST, int KIND>
+ResidentFn rpick_loss(bool loss) {
+  return loss ? resident_sweep_kernel<MODE, DEPTH, ST, KIND, true> : resident_sweep_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+ResidentFn rpick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? rpick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss)
+                               : rpick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
+template <int MODE, int DEPTH>
+ResidentFn rpick_store(int store, int kind, bool loss) {
+  return store == 0 ? rpick_kind<MODE, DEPTH, double>(kind, loss) : rpick_kind<MODE, DEPTH, float>(kind, loss);
+}
+ResidentFn rpick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return rpick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return rpick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return rpick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return rpick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return rpick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return rpick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
+}
+
 typedef void (*BatchStepFn)(Planes, const PairDesc*, const BatchState*, double, double*, double*, unsigned int*,
                             unsigned long long);
 template <int MODE, int DEPTH, typename ST, int KIND>
@@ -509,6 +585,16 @@ hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Plane
   if (!fn) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs)), dim3(kBlock), 0, stream, pl, desc, io, opt, ticket,
                      seq_host_dev, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_resident_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl, size_t n,
+                                 const ResidentRecord* rec_dev, double* host_pack_dev, unsigned long long first_cmd_seq,
+                                 unsigned long long first_pack_seq, unsigned long long idle_ticks, hipStream_t stream) {
+  ResidentFn fn = rpick(mode, depth, store, kind, loss);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(1), dim3(kBlock), 0, stream, pl, static_cast<unsigned long long>(n), rec_dev, host_pack_dev,
+                     first_cmd_seq, first_pack_seq, idle_ticks);
   return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 // Two matches per lane, 16-byte accesses (1 KiB per wave instruction) -- HBM-bound: 8-12 loads + 4-8 stores of
 // 8 B per match and iteration (96-128 B).
 #include "sba_device.hpp"
+#include "sba_resident.hpp"
 
 namespace sba {
 namespace {
@@ -71,21 +72,17 @@ struct DepthRegs {
   }
 };
 
-// Two resident 256-thread blocks per CU: 187 VGPRs hold both matches' temporaries and the whole register double buffer.
-// Holding the allocation to 3 / 4 blocks per CU (168 / 128 VGPRs, 84 / 244 B of scratch) was measured and is far worse:
-// 231-279 / 499-517 us per pass against 185 us (profiles/r03_depth_tune.log) -- the spills sit in the hot loop.
+// One lane's share of a pass: its pairs of matches pr, pr + stride, ... -- residuals, Jacobian, damped 2x2 solve, projected
+// candidate (stored to c1 / c2), candidate cost and gradient -- accumulated into the nine per-lane partial reductions
+// r[DEPTH_OUT_*].  Shared by the grid-wide kernel (stride = grid size) and the resident single-block kernel (stride = 256).
 template <typename ST>
-__global__ __launch_bounds__(256, 2) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
-                                                        const double* __restrict__ d2,
-                                                        double* __restrict__ c1, double* __restrict__ c2,
-                                                        double* __restrict__ sc1, double* __restrict__ sc2,
-                                                        DepthParams P, double* __restrict__ partials) {
-  __shared__ double red[4][DEPTH_OUT_COUNT];
-  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+__device__ __forceinline__ void depth_stream(const Planes& pl, const double* __restrict__ d1, const double* __restrict__ d2,
+                                             double* __restrict__ c1, double* __restrict__ c2, double* __restrict__ sc1,
+                                             double* __restrict__ sc2, const DepthParams& P, size_t pr, size_t stride,
+                                             double r[DEPTH_OUT_COUNT]) {
   const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
   const bool load_scale = !P.first_iteration;
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gdelta = 0, cand_gdelta = 0, gmax = 0, dmax = 0;
-  size_t pr = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   DepthRegs<ST> cur, nxt;
   if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, load_scale, pr);
   while (pr < npairs) {
@@ -156,18 +153,100 @@ __global__ __launch_bounds__(256, 2) void depth_step_kernel(Planes pl, const dou
     cur = nxt;
     pr = pn;
   }
+  r[0] = cost; r[1] = model; r[2] = cand_cost; r[3] = step2; r[4] = x2n; r[5] = gdelta; r[6] = cand_gdelta; r[7] = gmax; r[8] = dmax;
+}
+static_assert(DEPTH_OUT_COUNT == 9 && DEPTH_OUT_SUMS == 7, "depth_stream fills slots 0..6 (sums) and 7, 8 (maxima)");
+
+// Block-level fold of the per-lane partials: lanes by butterfly, the four waves in wave order; res[0..8] valid on
+// threads < DEPTH_OUT_COUNT after the call (which contains one barrier).
+__device__ __forceinline__ double depth_block_fold(const double r[DEPTH_OUT_COUNT], double (*red)[DEPTH_OUT_COUNT]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double r[DEPTH_OUT_COUNT] = {wave_sum(cost), wave_sum(model), wave_sum(cand_cost), wave_sum(step2), wave_sum(x2n),
-                                     wave_sum(gdelta), wave_sum(cand_gdelta), wave_max(gmax), wave_max(dmax)};
-  if (lane == 0)
-    for (int k = 0; k < DEPTH_OUT_COUNT; ++k) red[wave][k] = r[k];
+#pragma unroll
+  for (int k = 0; k < DEPTH_OUT_COUNT; ++k) {
+    const double v = k < DEPTH_OUT_SUMS ? wave_sum(r[k]) : wave_max(r[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
   __syncthreads();
+  double s = 0.0;
   if (threadIdx.x < DEPTH_OUT_COUNT) {
     const bool is_max = threadIdx.x >= DEPTH_OUT_SUMS;
-    double s = red[0][threadIdx.x];
+    s = red[0][threadIdx.x];
     for (int wv = 1; wv < 4; ++wv) s = is_max ? fmax(s, red[wv][threadIdx.x]) : s + red[wv][threadIdx.x];
-    partials[static_cast<size_t>(blockIdx.x) * DEPTH_ROW + threadIdx.x] = s;
   }
+  return s;
+}
+
+// Two resident 256-thread blocks per CU: 187 VGPRs hold both matches' temporaries and the whole register double buffer.
+// Holding the allocation to 3 / 4 blocks per CU (168 / 128 VGPRs, 84 / 244 B of scratch) was measured and is far worse:
+// 231-279 / 499-517 us per pass against 185 us (profiles/r03_depth_tune.log) -- the spills sit in the hot loop.
+template <typename ST>
+__global__ __launch_bounds__(256, 2) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
+                                                           const double* __restrict__ d2,
+                                                           double* __restrict__ c1, double* __restrict__ c2,
+                                                           double* __restrict__ sc1, double* __restrict__ sc2,
+                                                           DepthParams P, double* __restrict__ partials) {
+  __shared__ double red[4][DEPTH_OUT_COUNT];
+  double r[DEPTH_OUT_COUNT];
+  depth_stream<ST>(pl, d1, d2, c1, c2, sc1, sc2, P, static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x,
+                   static_cast<size_t>(gridDim.x) * blockDim.x, r);
+  const double s = depth_block_fold(r, red);
+  if (threadIdx.x < DEPTH_OUT_COUNT) partials[static_cast<size_t>(blockIdx.x) * DEPTH_ROW + threadIdx.x] = s;
+}
+
+// ---- resident evaluator of the d-only stage of ONE small problem (sba_resident.hpp) ------------------------------------------
+// One block, resident for the whole stage; per command one pass over all matches.  Command payload: [0] opcode,
+// [1..19] R, t, lambda, c, radius, 1 / radius, min / max diagonal, alpha, [20] flags (bit 0 first_iteration, bit 1
+// reuse_diagonal, bit 2 jacobi_scaling, bit 3 `flip`: the current depths are the b planes and the candidates go to the a
+// planes), [21] n (as bits).  Loop shape as resident_sweep_kernel.
+template <typename ST>
+__global__ __launch_bounds__(256, 2) void resident_depth_kernel(Planes pl, unsigned long long n_resident, double* __restrict__ a1,
+                                                               double* __restrict__ a2, double* __restrict__ b1,
+                                                               double* __restrict__ b2, double* __restrict__ sc1,
+                                                               double* __restrict__ sc2, const ResidentRecord* __restrict__ rec,
+                                                               double* __restrict__ host_pack, unsigned long long first_cmd_seq,
+                                                               unsigned long long first_pack_seq, unsigned long long idle_ticks) {
+  __shared__ double red[4][DEPTH_OUT_COUNT];
+  __shared__ double res_s[DEPTH_ROW];
+  __shared__ double cmd_s[kResidentPayload];
+  __shared__ int end_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) end_s = 0;
+  for (int trip = 0; trip < kResidentMaxTrips; ++trip) {
+    __syncthreads();                                   // B0: the previous pass's reductions are in res_s
+    if (tid < 64) {
+      if (trip > 0) resident_publish(host_pack, res_s, DEPTH_OUT_COUNT, first_pack_seq + static_cast<unsigned long long>(trip - 1));
+      int end = 0;
+      resident_wait_command(rec, first_cmd_seq + static_cast<unsigned long long>(trip), idle_ticks, cmd_s, &end);
+      if (tid == 0 && end) end_s = end;
+    }
+    __syncthreads();                                   // B1
+    if (end_s) break;
+    const int op = static_cast<int>(cmd_s[0]);
+    if (op != RESIDENT_OP_DEPTH) {
+      if (tid == 0) end_s = op == RESIDENT_OP_QUIT ? RESIDENT_END_QUIT : RESIDENT_END_BAD_OP;
+      break;
+    }
+    DepthParams P;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.R[k] = cmd_s[1 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.t[k] = cmd_s[10 + k];
+    P.lambda = cmd_s[13]; P.c = cmd_s[14]; P.radius = cmd_s[15]; P.inv_radius = cmd_s[16];
+    P.min_diagonal = cmd_s[17]; P.max_diagonal = cmd_s[18]; P.alpha = cmd_s[19];
+    const int flags = static_cast<int>(cmd_s[20]);
+    P.first_iteration = flags & 1; P.reuse_diagonal = (flags >> 1) & 1; P.jacobi_scaling = (flags >> 2) & 1; P.stream_stores = 0;
+    const bool flip = (flags >> 3) & 1;
+    unsigned long long n_cmd;
+    const double nd = cmd_s[21];
+    __builtin_memcpy(&n_cmd, &nd, sizeof(n_cmd));
+    P.n = n_cmd < n_resident ? n_cmd : n_resident;
+    double r[DEPTH_OUT_COUNT];
+    depth_stream<ST>(pl, flip ? b1 : a1, flip ? b2 : a2, flip ? a1 : b1, flip ? a2 : b2, sc1, sc2, P, static_cast<size_t>(tid), 256, r);
+    const double s = depth_block_fold(r, red);
+    if (tid < DEPTH_OUT_COUNT) res_s[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 64) resident_publish_end(host_pack, end_s ? end_s : RESIDENT_END_TRIPS);
 }
 
 // [nblocks][16] -> out[9]: sums of slots 0..6 and the maxima of slots 7, 8, in a fixed order.
@@ -227,6 +306,19 @@ DepthFn depth_pick(int store) { return store == 0 ? depth_step_kernel<double> : 
 
 hipError_t depth_blocks_per_cu(int store, int* blocks) {
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(depth_pick(store)), 256, 0);
+}
+
+hipError_t launch_resident_depth(int store, const Planes& pl, size_t n, double* a1, double* a2, double* b1, double* b2,
+                                 double* sc1, double* sc2, const ResidentRecord* rec_dev, double* host_pack_dev,
+                                 unsigned long long first_cmd_seq, unsigned long long first_pack_seq,
+                                 unsigned long long idle_ticks, hipStream_t stream) {
+  if (store == 0)
+    hipLaunchKernelGGL((resident_depth_kernel<double>), dim3(1), dim3(256), 0, stream, pl, static_cast<unsigned long long>(n), a1, a2,
+                       b1, b2, sc1, sc2, rec_dev, host_pack_dev, first_cmd_seq, first_pack_seq, idle_ticks);
+  else
+    hipLaunchKernelGGL((resident_depth_kernel<float>), dim3(1), dim3(256), 0, stream, pl, static_cast<unsigned long long>(n), a1, a2,
+                       b1, b2, sc1, sc2, rec_dev, host_pack_dev, first_cmd_seq, first_pack_seq, idle_ticks);
+  return hipGetLastError();
 }
 
 hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, const double* d2, double* c1,

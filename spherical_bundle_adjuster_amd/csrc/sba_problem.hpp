@@ -11,6 +11,7 @@
 #include "../../include/sba_hip.h"
 #include "sba_device.hpp"
 #include "sba_internal.hpp"
+#include "sba_resident.hpp"
 
 // ---- the handle ---------------------------------------------------------------------------------
 struct sba_problem {
@@ -65,6 +66,14 @@ struct sba_problem {
   int wall_clock_khz = 100000;            // rate of the device's constant wall clock (hipDeviceAttributeWallClockRate)
   unsigned long long* peer_sticky = nullptr;   // device word: some exchange timed out (never cleared while connected)
 
+  // resident evaluator for small problems (sba_resident.hpp): command record in mapped pinned host memory
+  sba::ResidentRecord* res_rec = nullptr;
+  sba::ResidentRecord* res_rec_dev = nullptr;
+  unsigned long long res_cmd_seq = 0;     // sequence number of the last command written
+  size_t resident_max_n = 8192;           // SBA_RESIDENT_MAX_N: largest problem the solve stages drive through a resident
+                                          // single-block kernel (0 = never); above it every sweep / pass is a launch
+  double resident_idle_s = 0.25;          // SBA_RESIDENT_IDLE_S: a resident kernel ends itself after this long without a command
+
   sba_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
   void* comm = nullptr;        // ncclComm_t
@@ -94,6 +103,33 @@ constexpr int kNcclFloat64 = 8;  // ncclDouble
 constexpr int kNcclSum = 0;      // ncclSum
 
 inline bool is_collective(const sba_problem* p) { return p->comm != nullptr || p->hook != nullptr || p->peer_ready; }
+
+// sba_resident.cpp -- one resident kernel serving one solve stage of a small, unsharded problem.  start_*() launches it,
+// call() sends a command and waits for its answer (restarting a kernel that ended itself: idle time-out, trip limit),
+// end() sends QUIT and waits, bounded, for the stream to drain; the destructor ends a session that is still open.
+bool resident_eligible(const sba_problem* p);
+class ResidentSession {
+ public:
+  explicit ResidentSession(sba_problem* p) : p_(p) {}
+  ResidentSession(const ResidentSession&) = delete;
+  ResidentSession& operator=(const ResidentSession&) = delete;
+  ~ResidentSession() { if (active_) (void)end(); }
+  int start_sweep(int mode, int depth_mode, bool loss);
+  int start_depth(double* a1, double* a2, double* b1, double* b2, double* sc1, double* sc2);
+  int call(const double* payload, int count, double* out, int out_count);
+  int end();
+  bool active() const { return active_; }
+
+ private:
+  int launch();
+  sba_problem* p_;
+  bool active_ = false;
+  bool depth_ = false;
+  int mode_ = 0, depth_mode_ = 0;
+  bool loss_ = true;
+  double *a1_ = nullptr, *a2_ = nullptr, *b1_ = nullptr, *b2_ = nullptr, *sc1_ = nullptr, *sc2_ = nullptr;
+  unsigned long long pending_cmd_ = 0, pending_pack_ = 0;   // what the next launched kernel waits for / answers with
+};
 
 // sba_transport.cpp
 int allreduce_pack(sba_problem* p);                                  // p->pack_dev (24 doubles), then hand-over to the host

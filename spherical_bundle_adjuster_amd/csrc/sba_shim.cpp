@@ -433,6 +433,13 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   if (const char* env = std::getenv("SBA_PUBLISH")) p->publish = std::strcmp(env, "0") != 0;
   SBA_HIP_TRY(hipEventCreate(&p->ev0));
   SBA_HIP_TRY(hipEventCreate(&p->ev1));
+  // resident evaluator for small problems: the command record the host writes and a resident kernel polls
+  SBA_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->res_rec), sizeof(sba::ResidentRecord),
+                            hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(p->res_rec, 0, sizeof(sba::ResidentRecord));
+  SBA_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->res_rec_dev), p->res_rec, 0));
+  if (const char* env = std::getenv("SBA_RESIDENT_MAX_N")) { const long v = std::atol(env); if (v >= 0) p->resident_max_n = static_cast<size_t>(v); }
+  if (const char* env = std::getenv("SBA_RESIDENT_IDLE_S")) { const double v = std::atof(env); if (v > 0.0 && v <= 10.0) p->resident_idle_s = v; }
   guard.p = nullptr;     // hand over
   *out = p;
   return SBA_OK;
@@ -461,6 +468,7 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->peer_sticky) (void)hipFree(p->peer_sticky);
   if (p->epi_scratch) (void)hipFree(p->epi_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
+  if (p->res_rec) (void)hipHostFree(p->res_rec);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -737,9 +745,37 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
   if (opt) o = *opt; else sba::lm_default_options(&o);
   double eval_seconds = 0.0;
   int eval_rc = SBA_OK;
+  // Small, unsharded problems (the reference's real sizes): ONE resident single-block kernel serves every sweep of this
+  // stage -- the host LM below is unchanged, only the evaluator talks to a kernel that is already running instead of
+  // launching two per iteration (sba_resident.hpp).  SBA_RESIDENT_MAX_N=0 keeps the launch-per-sweep path.
+  sba::shim::ResidentSession session(p);
+  if (sba::shim::resident_eligible(p)) {
+    SBA_HIP_TRY(hipSetDevice(p->device));
+    rc = session.start_sweep(mode, depth_mode, o.huber_delta > 0.0);
+    if (rc) return rc;
+  }
   auto evaluator = [&](const double r[3], const double t[3], sba_normal_eq* ne) -> bool {
     const auto t0 = std::chrono::steady_clock::now();
-    eval_rc = sba_problem_eval(p, mode, depth_mode, r, t, d1, d2, o.huber_delta, ne);
+    if (session.active()) {
+      sba::SweepParams prm;
+      make_params(p, depth_mode, r, t, d1, d2, o.huber_delta, &prm);
+      make_frame(p, mode, r);
+      double payload[44], raw[SBA_PACK_SIZE], pack[SBA_PACK_SIZE];
+      payload[0] = static_cast<double>(sba::RESIDENT_OP_SWEEP);
+      std::memcpy(payload + 1, &prm, 42 * sizeof(double));
+      const unsigned long long n_bits = prm.n;
+      std::memcpy(payload + 43, &n_bits, sizeof(double));
+      eval_rc = session.call(payload, 44, raw, SBA_PACK_SIZE);
+      if (eval_rc == SBA_OK) {
+        if (p->kind == SBA_KERNEL_FACTORED && mode != SBA_MODE_TRAN)
+          sba::moments_to_normal_pack(true, mode == SBA_MODE_RT, p->frame_B, p->frame_J, raw, pack);
+        else
+          std::memcpy(pack, raw, sizeof(pack));
+        sba::expand_pack(mode, pack, ne);
+      }
+    } else {
+      eval_rc = sba_problem_eval(p, mode, depth_mode, r, t, d1, d2, o.huber_delta, ne);
+    }
     eval_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return eval_rc == SBA_OK;
   };
@@ -747,9 +783,10 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
   sba_lm_summary* s = summary ? summary : &local;
   const int lm_rc = sba::lm_solve(mode, rot, tran, o, evaluator, s);
   s->seconds_eval = eval_seconds;
+  const int end_rc = session.end();
   if (eval_rc != SBA_OK) return eval_rc;  // message already set by the failing eval
   if (lm_rc != SBA_OK) return fail(lm_rc, "LM failed: non-finite or singular normal equations");
-  return SBA_OK;
+  return end_rc;
 }
 
 static int require_device(int device) {

@@ -120,15 +120,41 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     return SBA_OK;
   };
 
+  // Small, unsharded problem: one resident single-block kernel serves every pass of the stage (sba_resident.hpp); the
+  // step logic below is the same, a pass is a command instead of two launches.  The planes alternate as in the launch
+  // path: `flip` says that the work planes currently hold the depths and the problem's planes take the candidates.
+  sba::shim::ResidentSession session(p);
+  bool flip = false;
+  if (sba::shim::resident_eligible(p)) {
+    const int rc = session.start_depth(p->dplane[0], p->dplane[1], c1, c2, sc1, sc2);
+    if (rc) return rc;
+  }
+  auto resident_pass = [&](const sba::DepthPassRequest& rq) -> int {
+    double payload[22];
+    payload[0] = static_cast<double>(sba::RESIDENT_OP_DEPTH);
+    for (int k = 0; k < 9; ++k) payload[1 + k] = prm.R[k];
+    for (int k = 0; k < 3; ++k) payload[10 + k] = prm.t[k];
+    payload[13] = prm.lambda; payload[14] = prm.c; payload[15] = rq.radius; payload[16] = 1.0 / rq.radius;
+    payload[17] = prm.min_diagonal; payload[18] = prm.max_diagonal; payload[19] = rq.alpha;
+    payload[20] = static_cast<double>((rq.first ? 1 : 0) | (rq.keep_diagonal ? 2 : 0) | (prm.jacobi_scaling ? 4 : 0) | (flip ? 8 : 0));
+    const unsigned long long n_bits = n;
+    std::memcpy(payload + 21, &n_bits, sizeof(double));
+    return session.call(payload, 22, out, sba::DEPTH_OUT_COUNT);
+  };
+
   // The step logic (trust region + Ceres' projected line search) is a host state machine, sba_depth_solver.hpp: it
   // names the next pass, is fed the pass's reductions, and says when the candidate planes become the current depths.
   sba::DepthStageSolver solver;
   solver.start(o);
   while (!solver.done()) {
-    const int rc = pass(solver.request());
+    const int rc = session.active() ? resident_pass(solver.request()) : pass(solver.request());
     if (rc) return rc;
     solver.feed(out);
-    if (solver.take_candidate()) { std::swap(cur1, c1); std::swap(cur2, c2); }
+    if (solver.take_candidate()) { std::swap(cur1, c1); std::swap(cur2, c2); flip = !flip; }
+  }
+  {
+    const int rc = session.end();
+    if (rc) return rc;
   }
   *sum = solver.summary();
   sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

@@ -15,8 +15,12 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <thread>
+
 #include "../../include/sba_hip.h"
 #include "../../spherical_bundle_adjuster_amd/csrc/sba_device.hpp"
+#include "../../spherical_bundle_adjuster_amd/csrc/sba_problem.hpp"
 
 namespace {
 bool g_wedged = false;
@@ -51,7 +55,8 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(std::malloc(8)); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { blocking_call("hipStreamDestroy"); std::free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { blocking_call("hipStreamSynchronize"); return hipSuccess; }
-hipError_t hipStreamQuery(hipStream_t) { return g_wedged ? hipErrorNotReady : hipSuccess; }
+namespace sba { namespace { extern std::atomic<int> g_kernels_running; } }
+hipError_t hipStreamQuery(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(std::malloc(8)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
@@ -104,10 +109,77 @@ hipError_t launch_depth_step(int, const Planes&, const double*, const double*, d
   publish(host, 24, seq); return hipSuccess;
 }
 hipError_t launch_epipolar_moments(int, const Planes&, size_t, double*, int, double*, hipStream_t) { return hipSuccess; }
+// ---- the resident kernels, emulated by a host thread that speaks the device side of the protocol (sba_resident.hpp) -------
+// Same record decoding as resident_wait_command (check word per line), same publication order as resident_publish, same
+// ends (QUIT command, idle time-out, trip budget).  The "sweep" it answers with is a fixed function of the command's
+// payload, so the caller can tell that command k got answer k.  A launch on the mock's one stream runs in launch order:
+// a new emulated kernel first joins the previous one (a real stream serialises them the same way).
+namespace {
+std::thread g_kernel;
+std::atomic<int> g_kernels_launched{0}, g_kernels_running{0};
+int g_mock_trip_budget = kResidentMaxTrips;
+bool read_record(const ResidentRecord* rec, unsigned long long expect, double payload[kResidentPayload]) {
+  for (int l = 0; l < kResidentLines; ++l) {
+    const volatile unsigned long long* line = reinterpret_cast<const volatile unsigned long long*>(rec->w[l]);
+    unsigned long long w[8];
+    for (int k = 0; k < 8; ++k) w[k] = line[k];
+    unsigned long long x = w[7];
+    for (int k = 0; k < 7; ++k) x ^= resident_fold(w[k], k);
+    if (x != expect) return false;
+    for (int k = 0; k < 7; ++k) std::memcpy(&payload[7 * l + k], &w[k], 8);
+  }
+  return true;
+}
+void emulated_resident_kernel(const ResidentRecord* rec, double* host_pack, unsigned long long first_cmd, unsigned long long first_pack,
+                              unsigned long long idle_ticks, int khz, int want_op) {
+  volatile unsigned long long* words = reinterpret_cast<volatile unsigned long long*>(host_pack);
+  const double idle_s = static_cast<double>(idle_ticks) / (1e3 * khz);
+  int end = RESIDENT_END_TRIPS;
+  for (int trip = 0; trip < g_mock_trip_budget; ++trip) {
+    double payload[kResidentPayload];
+    const auto t0 = std::chrono::steady_clock::now();
+    bool got = false;
+    while (!(got = read_record(rec, first_cmd + trip, payload))) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > idle_s) break;
+      std::this_thread::yield();
+    }
+    if (!got) { end = RESIDENT_END_IDLE; break; }
+    const int op = static_cast<int>(payload[0]);
+    if (op == RESIDENT_OP_QUIT) { end = RESIDENT_END_QUIT; break; }
+    if (op != want_op) { end = RESIDENT_END_BAD_OP; break; }
+    for (int k = 0; k < 24; ++k) host_pack[k] = payload[1 + k] + 1000.0 * k;      // the "sums"
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    words[24] = first_pack + trip;
+  }
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  words[kResidentEndWord] = static_cast<unsigned long long>(end);
+  g_kernels_running.fetch_sub(1);
+}
+hipError_t launch_emulated(const ResidentRecord* rec, double* host_pack, unsigned long long first_cmd, unsigned long long first_pack,
+                           unsigned long long idle_ticks, int want_op) {
+  if (g_wedged) return hipSuccess;            // a wedged device never runs what is launched on it
+  if (g_kernel.joinable()) g_kernel.join();   // stream order
+  ++g_kernels_launched;
+  g_kernels_running.fetch_add(1);
+  g_kernel = std::thread(emulated_resident_kernel, rec, host_pack, first_cmd, first_pack, idle_ticks, 100000, want_op);
+  return hipSuccess;
+}
+}  // namespace
+hipError_t launch_resident_sweep(int, int, int, int, bool, const Planes&, size_t, const ResidentRecord* rec, double* host_pack,
+                                 unsigned long long first_cmd, unsigned long long first_pack, unsigned long long idle_ticks, hipStream_t) {
+  return launch_emulated(rec, host_pack, first_cmd, first_pack, idle_ticks, RESIDENT_OP_SWEEP);
+}
+hipError_t launch_resident_depth(int, const Planes&, size_t, double*, double*, double*, double*, double*, double*, const ResidentRecord* rec,
+                                 double* host_pack, unsigned long long first_cmd, unsigned long long first_pack,
+                                 unsigned long long idle_ticks, hipStream_t) {
+  return launch_emulated(rec, host_pack, first_cmd, first_pack, idle_ticks, RESIDENT_OP_DEPTH);
+}
 hipError_t launch_epipolar_subset_moments(int, const Planes&, size_t, const int*, int, int, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_keypoints_to_sphere(const uint8_t*, size_t, size_t, double, double, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_keypoints_to_planes(const uint8_t*, const uint8_t*, size_t, size_t, double, double, void* const*, int, hipStream_t) { return hipSuccess; }
 }  // namespace sba
+
+hipError_t hipStreamQuery(hipStream_t) { return (g_wedged || sba::g_kernels_running.load() > 0) ? hipErrorNotReady : hipSuccess; }
 
 #define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "wedge_harness: check failed: %s (line %d); last error: %s\n", #c, __LINE__, sba_last_error()); return 1; } } while (0)
 
@@ -195,6 +267,59 @@ int main() {
     REQUIRE(seconds_since(t0) < 0.5);
     REQUIRE(g_violations == 0);
     g_wedged = false;
+  }
+  // ---- resident evaluator: the host side of the protocol against a host thread that speaks the device side -----------------------
+  {
+    using sba::shim::ResidentSession;
+    sba_problem* p = nullptr;
+    REQUIRE(sba_problem_create(&p, 0, nullptr) == SBA_OK);
+    REQUIRE(sba_problem_upload(p, x.data(), x.data(), d12.data(), n, SBA_STORE_F64) == SBA_OK);
+    REQUIRE(sba::shim::resident_eligible(p));
+    p->resident_idle_s = 0.05;
+    const int launched0 = sba::g_kernels_launched.load();
+    double payload[44], got[24];
+    auto check = [&](ResidentSession& s, int k) -> bool {
+      payload[0] = sba::RESIDENT_OP_SWEEP;
+      for (int i = 1; i < 44; ++i) payload[i] = 0.25 * i + k;
+      if (s.call(payload, 44, got, 24) != SBA_OK) return false;
+      for (int i = 0; i < 24; ++i) if (got[i] != payload[1 + i] + 1000.0 * i) return false;
+      return true;
+    };
+    {
+      ResidentSession s(p);
+      REQUIRE(s.start_sweep(SBA_MODE_RT, SBA_DEPTH_PER_MATCH, true) == SBA_OK);
+      for (int k = 0; k < 200; ++k) REQUIRE(check(s, k));                       // back to back: one kernel serves them all
+      REQUIRE(sba::g_kernels_launched.load() == launched0 + 1);
+      std::this_thread::sleep_for(std::chrono::milliseconds(200));             // the host goes away: the kernel ends itself ...
+      REQUIRE(sba::g_kernels_running.load() == 0);
+      for (int k = 0; k < 5; ++k) REQUIRE(check(s, 1000 + k));                  // ... and is restarted on the pending command
+      REQUIRE(sba::g_kernels_launched.load() == launched0 + 2);
+      REQUIRE(s.end() == SBA_OK);
+      REQUIRE(sba::g_kernels_running.load() == 0);                              // QUIT was seen, the stream has drained
+    }
+    {
+      sba::g_mock_trip_budget = 7;                                             // trip budget used up mid-session: restarted too
+      ResidentSession s(p);
+      REQUIRE(s.start_sweep(SBA_MODE_ROT, SBA_DEPTH_UNIFORM, true) == SBA_OK);
+      for (int k = 0; k < 30; ++k) REQUIRE(check(s, k));
+      REQUIRE(sba::g_kernels_launched.load() >= launched0 + 2 + 4);
+      sba::g_mock_trip_budget = sba::kResidentMaxTrips;
+    }                                                                          // destructor ends the session
+    REQUIRE(sba::g_kernels_running.load() == 0);
+    {
+      ResidentSession s(p);                                                     // a kernel that never answers: bounded, poisons
+      REQUIRE(s.start_sweep(SBA_MODE_ROT, SBA_DEPTH_UNIFORM, true) == SBA_OK);
+      REQUIRE(check(s, 1));
+      g_wedged = true;                                                         // (restarts are swallowed like every launch)
+      std::this_thread::sleep_for(std::chrono::milliseconds(200));
+      payload[0] = sba::RESIDENT_OP_SWEEP;
+      REQUIRE(s.call(payload, 44, got, 24) == SBA_ERR_HIP);
+      REQUIRE(p->poisoned == 1);
+    }
+    REQUIRE(sba_problem_destroy(p) == SBA_ERR_HIP);
+    REQUIRE(g_violations == 0);
+    g_wedged = false;
+    if (sba::g_kernel.joinable()) sba::g_kernel.join();
   }
   // ---- and a healthy life cycle still frees everything (destroy returns SBA_OK) --------------------------------------------------
   {

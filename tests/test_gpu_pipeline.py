@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from helpers import ROOT
-from spherical_bundle_adjuster_amd import synthetic
+from spherical_bundle_adjuster_amd import api, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -109,6 +109,63 @@ def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
     assert np.abs(got_tran - t2).max() < 2e-5 * max(1, np.abs(t2).max())
     # and the guess itself is in the neighbourhood of the true rotation
     assert np.abs(rot0 - c.rot_true).max() < 0.2
+
+
+@pytest.mark.parametrize("n,store", [(7, api.STORE_F64), (63, api.STORE_F64), (2048, api.STORE_F64), (2049, api.STORE_F32),
+                                     (8192, api.STORE_F64)])
+def test_resident_evaluator_equals_the_launch_path(oracle, n, store, monkeypatch):
+    """Small problems (<= SBA_RESIDENT_MAX_N = 8192 matches: BASELINE config C1, the reference's real workload) are solved
+    with ONE resident single-block kernel per stage that the host LM / d-only state machine commands through mapped
+    memory (csrc/sba_resident.hpp) instead of two launches per sweep.  Same state machines, same per-match arithmetic;
+    only the fold order of the sums differs (one block instead of a grid + finalize kernel): all three stages must
+    agree with the launch-per-sweep path to rounding, with identical iteration / step / contraction counts -- and with
+    the oracle."""
+    c = synthetic.full_rt(n, seed=4200 + n, sigma=5e-4)
+    start = np.full((n, 2), 3.0)
+    res = {}
+    for name, max_n in (("resident", None), ("launch", "0")):
+        if max_n is None:
+            monkeypatch.delenv("SBA_RESIDENT_MAX_N", raising=False)
+        else:
+            monkeypatch.setenv("SBA_RESIDENT_MAX_N", max_n)
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, start, store=store)
+            d, sd = p.solve_depths(c.rot_init, c.tran_init)
+            r1, t1, s1 = p.solve(api.MODE_ROT, c.rot_init, c.tran_init, d[0, 0], d[1 % n, 0])
+            r2, t2, s2 = p.solve(api.MODE_TRAN, r1, t1, d[0, 0], d[1 % n, 0])
+            r3, t3, s3 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH,
+                                 options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+            res[name] = (d, sd, r1, s1, t2, s2, r3, t3, s3)
+    (d, sd, r1, s1, t2, s2, r3, t3, s3), (dL, sdL, r1L, s1L, t2L, s2L, r3L, t3L, s3L) = res["resident"], res["launch"]
+    assert (sd.num_iterations, sd.num_successful_steps, sd.num_line_search_steps, sd.termination) == \
+        (sdL.num_iterations, sdL.num_successful_steps, sdL.num_line_search_steps, sdL.termination)
+    assert np.abs(d - dL).max() <= 1e-10 * max(1.0, np.abs(dL).max())
+    for a, b in ((s1, s1L), (s2, s2L), (s3, s3L)):
+        assert (a.num_iterations, a.num_successful_steps, a.termination) == (b.num_iterations, b.num_successful_steps, b.termination)
+    assert np.abs(r1 - r1L).max() <= 1e-11 and np.abs(t2 - t2L).max() <= 1e-11
+    assert np.abs(r3 - r3L).max() <= 1e-10 and np.abs(t3 - t3L).max() <= 1e-10
+    if store == api.STORE_F64:
+        dref, sref, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, start)
+        assert rc == 0 and sd.num_iterations == sref.num_iterations and np.abs(d - dref).max() <= 1e-9 * max(1.0, np.abs(dref).max())
+        ro, to, so, rc = oracle.lm_solve(0, c.x1, c.x2, c.rot_init, c.tran_init, dref[0, 0], dref[1 % n, 0])
+        assert rc == 0 and s1.num_iterations == so.num_iterations and np.abs(r1 - ro).max() <= 1e-8
+
+
+def test_resident_kernel_survives_an_idle_host(oracle, monkeypatch):
+    """A resident kernel ends itself when no command arrives for SBA_RESIDENT_IDLE_S (a descheduled host thread must not
+    leave a spinning kernel behind); the next command restarts it.  Forced here with an idle limit of 2 ms and a verbose
+    LM whose per-iteration printing is slower than that now and then: the solve must still be the launch path's."""
+    c = synthetic.full_rt(3000, seed=4301)
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, c.d12)
+        r0, t0, s0 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+    monkeypatch.setenv("SBA_RESIDENT_IDLE_S", "0.000001")         # every gap between two commands is "idle"
+    with api.Problem(0) as p:
+        p.upload(c.x1, c.x2, c.d12)
+        r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        d, sd = p.solve_depths(c.rot_true, c.tran_true)
+    assert s1.num_iterations == s0.num_iterations and np.array_equal(r1, r0) and np.array_equal(t1, t0)
+    assert sd.termination.startswith("CONVERGENCE")
 
 
 def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
