@@ -10,7 +10,8 @@ correspondences with per-match depths (64 algorithmic bytes per evaluation: 2 x 
 components + 2 f64 depths), f64 arithmetic.  At N > 1: one GPU's shard of BASELINE config C4 ("100M
 correspondences sharded 8xMI355X") = 12.5M of the same correspondences per GPU, one RCCL all-reduce of the
 24-double pack per step (the collective north_star names; `--transport peer` selects the direct xGMI exchange).
-At N = 1 the line also carries `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
+At N = 1 the line also carries `c1`: BASELINE config C1 (the reference's real workload: 2 048 matches, initial guess + d-only +
+rot-only + tran-only end to end, GPU beside the oracle's pipeline on the host cores; `--no-c1-leg`), `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
 child run of `--workload c5` after the timed region (`--no-c5-leg` skips it), and `stages`: the 8-point initial guess and the
 bounded d-only stage of `solve_problem` on the resident problem (`--no-stage-leg`).
 At N > 1, only on request (`--peer-trial` / SBA_BENCH_PEER_TRIAL=1), the line also carries `peer_trial`: after the
@@ -79,6 +80,8 @@ def parse():
     ap.add_argument("--kernel", choices=["factored", "explicit"], default="factored")
     ap.add_argument("--no-stage-leg", action="store_true",
                     help="N = 1: skip the initial-guess / d-only-stage figures (`stages` in the line)")
+    ap.add_argument("--no-c1-leg", action="store_true",
+                    help="N = 1: skip the config-C1 figures (`c1` in the line: the reference's real workload end to end)")
     ap.add_argument("--no-c5-leg", action="store_true",
                     help="N = 1: skip the config-C5 figures (`c5` in the line: a child run of --workload c5)")
     ap.add_argument("--peer-trial", action="store_true",
@@ -348,6 +351,84 @@ def stage_leg(p, c, n: int):
                               "ms_total": s.seconds_total * 1e3, "us_per_pass": s.seconds_total / max(s.num_evaluations, 1) * 1e6,
                               "algorithmic_bytes_per_pass": n * 96, "termination": s.termination}
         return out
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
+
+def c1_leg(device_index: int, n: int = 2048, reps: int = 30):
+    """N = 1, after the timed region: BASELINE config C1 -- the reference's real workload, ~2 k matches, main/main.cpp's path
+    (reference main/main.cpp:29-32 -> do_bundle_adjustment -> initial_guess -> solve_problem: d-only -> rot-only ->
+    tran-only, spherical_bundle_adjuster.cpp:183-217).  End to end on the GPU through the C-ABI (upload, the initial guess
+    from the reference's own subsets, the three stages; problems of this size are served by a resident single-block
+    kernel per stage), wall clock, median of `reps`; beside it the same pipeline with a launch per sweep
+    (SBA_RESIDENT_MAX_N=0), and the oracle's pipeline on the host cores.  Iteration counts of all three must agree."""
+    import numpy as np
+    try:
+        from oracle import oracle_py as orc
+        from spherical_bundle_adjuster_amd import api, synthetic
+        c = synthetic.full_rt(n, seed=synthetic.BASE_SEED + 9, sigma=2e-4, outlier_fraction=0.02)
+        exp_d = 6.0
+        d0 = np.full((n, 2), exp_d)
+
+        def gpu_pipeline(p):
+            t = [time.perf_counter()]
+            p.upload(c.x1, c.x2, d0); t.append(time.perf_counter())
+            orc.c_srand(1)            # a fresh process's rand() state: the subsets the reference's main() would draw
+            e, tv, ncand = p.initial_guess_reference(80, 0.25); t.append(time.perf_counter())
+            rot0, tran0 = -e, tv                                                   # .cpp:330-331
+            d, sd = p.solve_depths(rot0, tran0); t.append(time.perf_counter())
+            r1, t1, s1 = p.solve(api.MODE_ROT, rot0, tran0, d[0, 0], d[1, 0]); t.append(time.perf_counter())
+            r2, t2, s2 = p.solve(api.MODE_TRAN, r1, t1, d[0, 0], d[1, 0]); t.append(time.perf_counter())
+            return np.diff(t) * 1e6, (sd.num_iterations, sd.num_line_search_steps, s1.num_iterations, s2.num_iterations), (r2, t2)
+
+        def measure(max_n):
+            old = os.environ.get("SBA_RESIDENT_MAX_N")
+            if max_n is None:
+                os.environ.pop("SBA_RESIDENT_MAX_N", None)
+            else:
+                os.environ["SBA_RESIDENT_MAX_N"] = max_n
+            try:
+                with api.Problem(device_index) as p:
+                    gpu_pipeline(p); gpu_pipeline(p)
+                    runs = [gpu_pipeline(p) for _ in range(reps)]
+            finally:
+                if old is None:
+                    os.environ.pop("SBA_RESIDENT_MAX_N", None)
+                else:
+                    os.environ["SBA_RESIDENT_MAX_N"] = old
+            us = np.median(np.array([r[0] for r in runs]), axis=0)
+            return {"total_us": float(us.sum()), "upload_us": float(us[0]), "initial_guess_us": float(us[1]), "d_only_us": float(us[2]),
+                    "rot_only_us": float(us[3]), "tran_only_us": float(us[4])}, runs[-1][1], runs[-1][2]
+        resident, counts_r, (rot_r, tran_r) = measure(None)
+        launch, counts_l, (rot_l, tran_l) = measure("0")
+        # the oracle's pipeline on the host (numpy 8-point recipe on the same subsets + the C++ restatement of the three stages)
+        cores = min(orc.num_procs(), usable_cores())
+        cpu_runs = []
+        for _ in range(3):
+            t = [time.perf_counter()]
+            subsets = orc.reference_trial_subsets(n, 80, reseed=True)
+            e, tv, _ = orc.initial_guess_recipe(c.x1, c.x2, subsets); t.append(time.perf_counter())
+            rot0, tran0 = -e.astype(np.float64), np.asarray(tv, dtype=np.float64)
+            dd, sdd, _ = orc.depth_solve(c.x1, c.x2, rot0, tran0, d0); t.append(time.perf_counter())
+            r1, t1, s1, _ = orc.lm_solve(0, c.x1, c.x2, rot0, tran0, dd[0, 0], dd[1, 0]); t.append(time.perf_counter())
+            r2, t2, s2, _ = orc.lm_solve(1, c.x1, c.x2, r1, t1, dd[0, 0], dd[1, 0]); t.append(time.perf_counter())
+            cpu_runs.append((np.diff(t) * 1e6, (sdd.num_iterations, sdd.num_line_search_steps, s1.num_iterations, s2.num_iterations), (r2, t2)))
+        cus = np.median(np.array([r[0] for r in cpu_runs]), axis=0)
+        counts_c, (rot_c, tran_c) = cpu_runs[-1][1], cpu_runs[-1][2]
+        # the product's T_vec sign may differ from numpy's (the reference never resolves it either): compare the rotation, and
+        # the translation only when the 8-point T agreed in sign
+        return {"ok": True, "matches": n, "reps": reps,
+                "gpu_resident": resident, "gpu_launch_per_sweep": launch,
+                "cpu_oracle": {"total_us": float(cus.sum()), "initial_guess_us": float(cus[0]), "d_only_us": float(cus[1]),
+                               "rot_only_us": float(cus[2]), "tran_only_us": float(cus[3]), "cores": cores,
+                               "what": "numpy restatement of initial_guess on the same subsets + oracle/sba_oracle.cpp stages"},
+                "iterations": {"order": "d-only, d-only line-search contractions, rot-only, tran-only",
+                               "gpu_resident": counts_r, "gpu_launch_per_sweep": counts_l, "cpu_oracle": counts_c,
+                               "equal": bool(counts_r == counts_l == counts_c)},
+                "max_abs_rot_diff_gpu_vs_cpu": float(np.abs(rot_r - rot_c).max()),
+                "max_abs_rot_diff_resident_vs_launch": float(np.abs(rot_r - rot_l).max()),
+                "what": "BASELINE config C1 (2 048 synthetic matches): upload -> initial guess (reference's own subsets) -> "
+                        "d-only -> rot-only -> tran-only through the C-ABI, wall clock in microseconds (Python call overhead included)"}
     except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
@@ -655,6 +736,8 @@ def main():
             out["scaling_reference"] = scaling_reference(api, synthetic, c, seed, device_index, a)
         if world == 1 and not rehearsal and not a.no_stage_leg and rt:
             out["stages"] = stage_leg(p, c, a.n)
+        if world == 1 and not rehearsal and not a.no_c1_leg:
+            out["c1"] = c1_leg(device_index)
         if world == 1 and not rehearsal and not a.no_c5_leg and rt and a.store == "f64":
             p.close()                       # the child gets the GPU to itself
             out["c5"] = c5_leg(a.steps, a.warmup)

@@ -265,3 +265,39 @@ def c_srand(seed: int) -> None:
 
 def c_rand() -> int:
     return int(lib().orc_rand())
+
+
+def initial_guess_recipe(x1: np.ndarray, x2: np.ndarray, subsets: np.ndarray):
+    """The reference's initial_guess (spherical_bundle_adjuster.cpp:118-181) restated in numpy on GIVEN subsets (rows of
+    `subsets` = the match indices of one trial): explicit rows kron(left, right) (.cpp:53-68), LAPACK SVD, last row of vt (for
+    fewer than 9 rows that is row m - 1 of the economy vt, as cv::SVDecomp returns it), rank-2 projection (.cpp:75-80),
+    R1 / R2 / t as cv::decomposeEssentialMat builds them, float32 Euler angles (rot2euler returns cv::Vec3f), validity
+    |angle| < 1.57 (.cpp:101-115), 20-80 % trimmed-mean consensus (.cpp:162-180).  Returns (R_vec_out, T_vec_out, number
+    of candidates) or (None, None, 0).  Test infrastructure, like everything under oracle/."""
+    def euler_of(R):
+        sy = np.hypot(R[0, 0], R[1, 0])
+        return np.array([np.arctan2(R[2, 1], R[2, 2]), np.arctan2(-R[2, 0], sy), np.arctan2(R[1, 0], R[0, 0])])
+    A = (x1[:, :, None] * x2[:, None, :]).reshape(len(x1), 9)
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    cands, tvecs = [], []
+    for idx in subsets:
+        vt = np.linalg.svd(A[idx], full_matrices=False)[2]
+        E = vt[-1].reshape(3, 3)
+        U, s, Vt = np.linalg.svd(E)
+        U, s, Vt = np.linalg.svd(U @ np.diag([s[0], s[1], 0.0]) @ Vt)
+        if np.linalg.det(U) < 0:
+            U = -U
+        if np.linalg.det(Vt) < 0:
+            Vt = -Vt
+        for R in (U @ W @ Vt, U @ W.T @ Vt):
+            e = euler_of(R).astype(np.float32)
+            if np.abs(e).max() < 1.57:
+                cands.append(e)
+                tvecs.append(U[:, 2])
+    c = np.array(cands, dtype=np.float32)
+    if len(c) == 0:
+        return None, None, 0
+    d = np.sort(np.linalg.norm((c[:, None, :] - c[None, :, :]).astype(np.float64), axis=2), axis=1)
+    lo, hi = int(len(c) * 0.2), int(len(c) * 0.8)
+    pick = int(np.argmin(d[:, lo:hi].mean(axis=1)))
+    return c[pick], tvecs[pick], len(c)

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kBlock) void resident_sweep_kernel(Planes pl, unsig
   __shared__ int end_s;
   const int tid = threadIdx.x;
   if (tid == 0) end_s = 0;
-  for (int trip = 0; trip < kResidentMaxTrips; ++trip) {
+  int trip = 0;
+  for (; trip < kResidentMaxTrips; ++trip) {
     __syncthreads();                                   // B0: the previous trip's sums are complete
     if (tid < 64) {                                    // wave 0: answer, then wait for the next command
       if (trip > 0) resident_publish(host_pack, raw_s, 24, first_pack_seq + static_cast<unsigned long long>(trip - 1));
@@ -453,7 +454,11 @@ __global__ __launch_bounds__(kBlock) void resident_sweep_kernel(Planes pl, unsig
     block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, 0, n, prm, wave_out, raw_s);
   }
   __syncthreads();
-  if (tid < 64) resident_publish_end(host_pack, end_s ? end_s : RESIDENT_END_TRIPS);
+  if (tid < 64) {
+    // trip budget used up: the last trip's answer has not been published yet (answers go out at the top of the next trip)
+    if (trip == kResidentMaxTrips) resident_publish(host_pack, raw_s, 24, first_pack_seq + static_cast<unsigned long long>(trip - 1));
+    resident_publish_end(host_pack, end_s ? end_s : RESIDENT_END_TRIPS);
+  }
 }
 
 // ---- batch kernel table (same template axes as the single-problem sweep) ---------------------------------------

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256, 2) void resident_depth_kernel(Planes pl, unsig
   __shared__ int end_s;
   const int tid = threadIdx.x;
   if (tid == 0) end_s = 0;
-  for (int trip = 0; trip < kResidentMaxTrips; ++trip) {
+  int trip = 0;
+  for (; trip < kResidentMaxTrips; ++trip) {
     __syncthreads();                                   // B0: the previous pass's reductions are in res_s
     if (tid < 64) {
       if (trip > 0) resident_publish(host_pack, res_s, DEPTH_OUT_COUNT, first_pack_seq + static_cast<unsigned long long>(trip - 1));
@@ -246,7 +247,11 @@ __global__ __launch_bounds__(256, 2) void resident_depth_kernel(Planes pl, unsig
     if (tid < DEPTH_OUT_COUNT) res_s[tid] = s;
   }
   __syncthreads();
-  if (tid < 64) resident_publish_end(host_pack, end_s ? end_s : RESIDENT_END_TRIPS);
+  if (tid < 64) {
+    // trip budget used up: the last trip's answer has not been published yet (answers go out at the top of the next trip)
+    if (trip == kResidentMaxTrips) resident_publish(host_pack, res_s, DEPTH_OUT_COUNT, first_pack_seq + static_cast<unsigned long long>(trip - 1));
+    resident_publish_end(host_pack, end_s ? end_s : RESIDENT_END_TRIPS);
+  }
 }
 
 // [nblocks][16] -> out[9]: sums of slots 0..6 and the maxima of slots 7, 8, in a fixed order.

@@ -194,3 +194,11 @@ def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
     assert c5["lm"]["all_converged"] and c5["equi2cube"]["frames"] == 512
     st = b["stages"]
     assert st["ok"] and st["depth_stage"]["termination"].startswith("CONVERGENCE") and st["initial_guess_ms_80_trials"] > 0
+    # config C1, the reference's real workload end to end: resident kernels, launch per sweep and the oracle on the host
+    # take the same numbers of iterations and land on the same rotation
+    c1 = b["c1"]
+    assert c1["ok"], c1
+    assert c1["iterations"]["equal"], c1["iterations"]
+    assert c1["max_abs_rot_diff_gpu_vs_cpu"] < 1e-6 and c1["max_abs_rot_diff_resident_vs_launch"] < 1e-10
+    assert 0 < c1["gpu_resident"]["total_us"] and 0 < c1["cpu_oracle"]["total_us"]
+    assert b["cold"]["value"] > 0

@@ -281,30 +281,9 @@ def test_reference_subsets_equal_libstdcxx_random_shuffle(oracle, n):
 
 
 def _recipe_on_subsets(x1, x2, subsets):
-    """The reference's initial_guess (.cpp:118-181) in numpy on GIVEN subsets: explicit A, LAPACK SVD, last row of vt (for
-    fewer than 9 rows that is row m - 1 of the economy vt, as cv::SVDecomp returns it), rank 2, R1 / R2, float32 Euler
-    angles, validity, 20-80 % trimmed-mean consensus."""
-    A = (x1[:, :, None] * x2[:, None, :]).reshape(len(x1), 9)
-    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
-    cands, tvecs = [], []
-    for idx in subsets:
-        vt = np.linalg.svd(A[idx], full_matrices=False)[2]
-        E = vt[-1].reshape(3, 3)
-        U, s, Vt = np.linalg.svd(E)
-        U, s, Vt = np.linalg.svd(U @ np.diag([s[0], s[1], 0.0]) @ Vt)
-        if np.linalg.det(U) < 0: U = -U
-        if np.linalg.det(Vt) < 0: Vt = -Vt
-        for R in (U @ W @ Vt, U @ W.T @ Vt):
-            e = euler_of(R).astype(np.float32)
-            if np.abs(e).max() < 1.57:
-                cands.append(e); tvecs.append(U[:, 2])
-    c = np.array(cands, dtype=np.float32)
-    if len(c) == 0:
-        return None, None, 0
-    d = np.sort(np.linalg.norm((c[:, None, :] - c[None, :, :]).astype(np.float64), axis=2), axis=1)
-    lo, hi = int(len(c) * 0.2), int(len(c) * 0.8)
-    pick = int(np.argmin(d[:, lo:hi].mean(axis=1)))
-    return c[pick], tvecs[pick], len(c)
+    """The reference's initial_guess in numpy on GIVEN subsets (explicit A, LAPACK SVD): oracle/oracle_py.py."""
+    from oracle import oracle_py
+    return oracle_py.initial_guess_recipe(x1, x2, subsets)
 
 
 def subset_moments(x1, x2, subsets):

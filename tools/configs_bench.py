@@ -22,7 +22,7 @@ print("`python bench.py <args>` on one MI355X, default pre-conditioning (60 ms).
 print("| run | matches | mode/storage/kernel | evals/s (host-synchronous steps) | step us | sweep kernel us (min..max per launch) | algorithmic GB/s | % of 8 TB/s | LM iters/s | CPU faithful evals/s |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for name, args in RUNS:
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args + ["--no-c5-leg", "--no-stage-leg"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args + ["--no-c5-leg", "--no-stage-leg", "--no-c1-leg", "--no-scaling-reference"], capture_output=True, text=True, timeout=600)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not line:
         print(f"| {name} | FAILED rc={r.returncode} {r.stderr[-200:]!r} |")

@@ -7,7 +7,7 @@ STEPS=${2:-50}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-c5-leg --no-stage-leg"
+ARGS="bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-c5-leg --no-stage-leg --no-c1-leg --no-scaling-reference --no-cold-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err || exit 2
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 $ARGS > $OUT/bench_write.json 2> $OUT/write.err || exit 3
