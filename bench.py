@@ -373,7 +373,7 @@ def c1_leg(device_index: int, n: int = 2048, reps: int = 30):
         def gpu_pipeline(p):
             t = [time.perf_counter()]
             p.upload(c.x1, c.x2, d0); t.append(time.perf_counter())
-            orc.c_srand(1)            # a fresh process's rand() state: the subsets the reference's main() would draw
+            api.reference_rand_seed(1)   # a fresh process's (never-seeded) rand() stream: the subsets the reference's main() would draw
             e, tv, ncand = p.initial_guess_reference(80, 0.25); t.append(time.perf_counter())
             rot0, tran0 = -e, tv                                                   # .cpp:330-331
             d, sd = p.solve_depths(rot0, tran0); t.append(time.perf_counter())

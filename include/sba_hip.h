@@ -341,13 +341,22 @@ int sba_problem_initial_guess(sba_problem* p, int trials, double subset_fraction
                               double rot_euler[3], double tran[3], int* num_candidates);
 
 /* ---- the same initial guess from the REFERENCE'S OWN random subsets (small problems) ------------------------- */
+/* The random stream behind it.  The reference shuffles with std::random_shuffle on rand(), which it never seeds: glibc's
+ * generator in its srand(1) state.  The library keeps its OWN copy of that generator (same algorithm, same values --
+ * pinned against the real rand() by the tests), starting in the never-seeded state and running on from call to call like
+ * the reference's stream does from image pair to image pair.  It does not borrow the process's rand(): once HIP is
+ * initialised that stream is no longer the caller's alone (libhsa-runtime64 imports srand / rand).  SBA_GUESS_RAND=libc in
+ * the environment switches to the process's rand() -- then draws made by other code of the process (a FLANN matcher's
+ * kd-trees, as in the reference's own process) count, and so do the ROCm runtime's.
+ * sba_reference_rand_seed(1) puts the stream back into the never-seeded state (any seed: as srand(seed));
+ * sba_reference_rand_next() draws one value, as rand() would.                                                    */
+int sba_reference_rand_seed(unsigned int seed);
+int sba_reference_rand_next(void);
 /* Host-only (no device needed): the match indices the reference's `trials` trials draw for a problem of n matches --
- * random_array (spherical_bundle_adjuster.hpp:182-211: std::iota + std::random_shuffle on the never-seeded process-wide
- * rand() stream) constructed once per trial, its first sample_n = (int)(n * subset_fraction) entries used
- * (spherical_bundle_adjuster.cpp:130-141).  indices: int[trials][sample_n].  Draws (n - 1) values per trial from
- * std::rand() of THIS process in libstdc++'s order, exactly what the reference's call would consume at this point of the
- * process -- so call it where the reference calls initial_guess, from that thread.  *sample_n_out receives sample_n
- * (pass indices = NULL to query it without drawing).                                                            */
+ * random_array (spherical_bundle_adjuster.hpp:182-211: std::iota + std::random_shuffle) constructed once per trial, its
+ * first sample_n = (int)(n * subset_fraction) entries used (spherical_bundle_adjuster.cpp:130-141).  indices:
+ * int[trials][sample_n].  Draws (n - 1) values per trial from the stream above, in libstdc++'s order.  *sample_n_out
+ * receives sample_n (pass indices = NULL to query it without drawing).                                          */
 int sba_reference_trial_subsets(int n, int trials, double subset_fraction, int* indices, int* sample_n_out);
 /* Device part: A^T A of the rows kron(left_i, right_i) over each trial's index list.  indices: int[trials][sample_n]
  * (host), every entry < n; moments: double[trials][45] (host; upper triangle, row-major a <= b).  Single-GPU problems

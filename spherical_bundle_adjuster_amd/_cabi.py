@@ -115,6 +115,8 @@ SIGNATURES = {
     "sba_initial_guess_from_moments": (C.c_int, [_dp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp,
                                                  C.POINTER(C.c_int)]),
     "sba_problem_initial_guess": (C.c_int, [_vp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp, C.POINTER(C.c_int)]),
+    "sba_reference_rand_seed": (C.c_int, [C.c_uint]),
+    "sba_reference_rand_next": (C.c_int, []),
     "sba_reference_trial_subsets": (C.c_int, [C.c_int, C.c_int, C.c_double, _vp, C.POINTER(C.c_int)]),
     "sba_problem_epipolar_subset_moments": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp]),
     "sba_problem_initial_guess_reference": (C.c_int, [_vp, C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_int)]),

@@ -482,9 +482,19 @@ def initial_guess_from_moments(groups, trials: int = 80, subset_fraction: float 
     return e, t, n.value
 
 
+def reference_rand_seed(seed: int = 1) -> None:
+    """Reset the library's copy of the reference's rand() stream (1 = the never-seeded state a fresh process starts in)."""
+    lib = cabi.load_library()
+    cabi.check(lib, lib.sba_reference_rand_seed(seed))
+
+
+def reference_rand_next() -> int:
+    return int(cabi.load_library().sba_reference_rand_next())
+
+
 def reference_trial_subsets(n: int, trials: int = 80, subset_fraction: float = 0.25) -> np.ndarray:
-    """Host-only: (trials, int(n * subset_fraction)) match indices the reference's trials draw from THIS process's rand()
-    stream at this point (sba_reference_trial_subsets)."""
+    """Host-only: (trials, int(n * subset_fraction)) match indices the reference's trials draw from the library's copy of
+    the reference's rand() stream at this point (sba_reference_trial_subsets)."""
     lib = cabi.load_library()
     m = C.c_int(0)
     cabi.check(lib, lib.sba_reference_trial_subsets(n, trials, subset_fraction, None, C.byref(m)))

@@ -14,13 +14,19 @@
 // sampling cannot be reproduced across C libraries anyway); everything after the null vector follows the reference
 // step by step.  All of it is tiny 9x9 / 3x3 host work.
 //
-// REFERENCE SAMPLING (small problems, round 3): the reference's own subsets CAN be reproduced where it matters -- in the
-// process the reference's main() runs in.  random_array (.hpp:182-211) is std::iota + std::random_shuffle, and
-// libstdc++'s random_shuffle(first, last) is `for i in 1..n-1: swap(a[i], a[std::rand() % (i + 1)])` on the process-wide
-// rand() stream.  reference_trial_subsets() below draws from that very stream in that very order (80 permutations of
-// match indices, the first int(n * 0.25) entries each, .cpp:130-141), so a process that swaps this library in for the
-// Ceres path consumes rand() exactly like the reference and every trial solves from the reference's own matches.  The
-// device then accumulates A^T A per trial from the index lists (sba_epipolar.hip: epipolar_subset_moments_kernel).
+// REFERENCE SAMPLING (small problems, round 3): the reference's own subsets can be reproduced.  random_array (.hpp:182-211)
+// is std::iota + std::random_shuffle, and libstdc++'s random_shuffle(first, last) is
+// `for i in 1..n-1: swap(a[i], a[std::rand() % (i + 1)])` on the process-wide rand() stream, which the reference never
+// seeds: glibc's additive-feedback generator in its srand(1) state.  reference_trial_subsets() below draws in that very
+// order (80 permutations of match indices, the first int(n * 0.25) entries each, .cpp:130-141) from a stream with
+// exactly those values -- by default a PRIVATE re-implementation of glibc's generator (GlibcRand: identical output,
+// pinned against the real rand() in tests/test_initial_guess_cpu.py), not the process's own rand(): a process that has
+// initialised HIP no longer owns that stream (libhsa-runtime64 imports srand() and rand()), so borrowing it would make the
+// subsets depend on what the ROCm runtime happened to draw.  The private stream starts where a never-seeded process
+// that has drawn nothing starts, and runs on from call to call like the reference's would across image pairs;
+// SBA_GUESS_RAND=libc switches to the process's rand() for integrators who want the matcher's draws (FLANN's kd-trees
+// call rand()) to count as they do in the reference.  The device then accumulates A^T A per trial from the index lists
+// (sba_epipolar.hip: epipolar_subset_moments_kernel).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -456,18 +462,51 @@ inline GuessResult initial_guess_from_groups(const double* groups, int trials, d
 // sample_n = int(match_size * 0.25) like `int sample_n = match_size*0.25;` (.cpp:133).
 inline int reference_sample_size(int n, double fraction = 0.25) { return static_cast<int>(n * fraction); }
 
-// out[trial * sample_n + k] = the k-th index trial `trial` draws.  Consumes (n - 1) values of the PROCESS-WIDE std::rand()
-// stream per trial, in the order libstdc++'s std::random_shuffle(first, last) does:
+// glibc's rand() / random() -- TYPE_3, the default: r[i] = r[i-3] + r[i-31] over 32-bit words, output r >> 1, state filled from
+// the seed by the Lehmer generator 16807 x mod (2^31 - 1) and warmed up by 310 discarded steps (glibc stdlib/random_r.c:
+// __srandom_r, __random_r) -- restated so that the library owns a stream with the reference's values.  seed 1 = the state of a
+// process that never called srand().
+class GlibcRand {
+ public:
+  explicit GlibcRand(unsigned seed = 1) { reseed(seed); }
+  void reseed(unsigned seed) {
+    if (seed == 0) seed = 1;
+    int32_t word = static_cast<int32_t>(seed);
+    r_[0] = static_cast<uint32_t>(word);
+    for (int i = 1; i < 31; ++i) {
+      const long hi = word / 127773, lo = word % 127773;           // 16807 * word mod 2147483647 without overflow
+      long w = 16807 * lo - 2836 * hi;
+      if (w < 0) w += 2147483647;
+      word = static_cast<int32_t>(w);
+      r_[i] = static_cast<uint32_t>(word);
+    }
+    f_ = 3; b_ = 0;
+    for (int i = 0; i < 310; ++i) (void)next();
+  }
+  int next() {                                                       // what rand() returns: 0 .. RAND_MAX = 2^31 - 1
+    r_[f_] += r_[b_];
+    const uint32_t v = r_[f_] >> 1;
+    f_ = (f_ + 1) % 31; b_ = (b_ + 1) % 31;
+    return static_cast<int>(v);
+  }
+
+ private:
+  uint32_t r_[31];
+  int f_ = 3, b_ = 0;
+};
+
+// out[trial * sample_n + k] = the k-th index trial `trial` draws.  Consumes (n - 1) values of `next_rand` per trial, in the
+// order libstdc++'s std::random_shuffle(first, last) does:
 //     for (i = first + 1; i != last; ++i) { j = first + std::rand() % ((i - first) + 1); if (i != j) iter_swap(i, j); }
-// -- a fresh permutation of 0..n-1 per trial (random_array's constructor), its first sample_n entries used.  Not
-// thread-safe by nature (rand() is process state): call it from the thread the reference would call initial_guess on.
-inline void reference_trial_subsets(int n, int trials, double fraction, int* out) {
+// -- a fresh permutation of 0..n-1 per trial (random_array's constructor), its first sample_n entries used.
+template <typename NextRand>
+inline void reference_trial_subsets(int n, int trials, double fraction, int* out, NextRand next_rand) {
   const int sample_n = reference_sample_size(n, fraction);
   std::vector<int> perm(static_cast<size_t>(std::max(n, 0)));
   for (int trial = 0; trial < trials; ++trial) {
     for (int i = 0; i < n; ++i) perm[i] = i;                                  // std::iota
     for (int i = 1; i < n; ++i) {                                             // std::random_shuffle, libstdc++
-      const int j = std::rand() % (i + 1);
+      const int j = next_rand() % (i + 1);
       if (i != j) std::swap(perm[i], perm[j]);
     }
     for (int k = 0; k < sample_n; ++k) out[static_cast<size_t>(trial) * sample_n + k] = perm[k];

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "sba_depth_solver.hpp"
 #include "sba_epipolar.hpp"
@@ -228,11 +229,38 @@ int sba_initial_guess_from_moments(const double* groups, int trials, double subs
   return SBA_OK;
 }
 
+namespace {
+// The stream the reference's random_array draws from (see sba_epipolar.hpp): by default the library's own copy of glibc's
+// generator in its never-seeded state, running on across calls; SBA_GUESS_RAND=libc: the process's rand().
+std::mutex g_ref_rand_mutex;
+sba::epi::GlibcRand g_ref_rand(1);
+bool use_libc_rand() {
+  const char* env = std::getenv("SBA_GUESS_RAND");
+  return env && std::strcmp(env, "libc") == 0;
+}
+void draw_reference_subsets(int n, int trials, double fraction, int* indices) {
+  std::lock_guard<std::mutex> lock(g_ref_rand_mutex);
+  if (use_libc_rand()) sba::epi::reference_trial_subsets(n, trials, fraction, indices, [] { return std::rand(); });
+  else sba::epi::reference_trial_subsets(n, trials, fraction, indices, [] { return g_ref_rand.next(); });
+}
+}  // namespace
+
+int sba_reference_rand_seed(unsigned int seed) {
+  std::lock_guard<std::mutex> lock(g_ref_rand_mutex);
+  if (use_libc_rand()) std::srand(seed); else g_ref_rand.reseed(seed);
+  return SBA_OK;
+}
+
+int sba_reference_rand_next(void) {
+  std::lock_guard<std::mutex> lock(g_ref_rand_mutex);
+  return use_libc_rand() ? std::rand() : g_ref_rand.next();
+}
+
 int sba_reference_trial_subsets(int n, int trials, double subset_fraction, int* indices, int* sample_n_out) {
   if (n < 0 || trials < 0 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
     return sba::set_error(SBA_ERR_INVALID_ARG, "bad n / trials / subset_fraction");
   if (sample_n_out) *sample_n_out = sba::epi::reference_sample_size(n, subset_fraction);
-  if (indices) sba::epi::reference_trial_subsets(n, trials, subset_fraction, indices);
+  if (indices) draw_reference_subsets(n, trials, subset_fraction, indices);
   return SBA_OK;
 }
 
@@ -281,7 +309,7 @@ int sba_problem_initial_guess_reference(sba_problem* p, int trials, double subse
   if (sample_n < 1)
     return sba::set_error(SBA_ERR_INVALID_ARG, "%d matches give an empty subset (the reference's cv::SVDecomp of a 0 x 9 matrix fails too)", n);
   std::vector<int> indices(static_cast<size_t>(trials) * sample_n);
-  sba::epi::reference_trial_subsets(n, trials, subset_fraction, indices.data());
+  draw_reference_subsets(n, trials, subset_fraction, indices.data());
   std::vector<double> moments(static_cast<size_t>(trials) * sba::epi::kMom);
   const int rc = sba_problem_epipolar_subset_moments(p, indices.data(), trials, sample_n, moments.data());
   if (rc) return rc;

@@ -96,9 +96,9 @@ def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
     x1 = oracle.keypoints_to_sphere(kl, W, H); x2 = oracle.keypoints_to_sphere(kr, W, H)
     with api.Problem(0) as p:
         p.upload(x1, x2)
-        # the CLI is a fresh process: never-seeded rand(), nothing drawn before initial_guess -- the reference's own
-        # subsets (the mirror class's default up to 65 536 matches).  Same state here: srand(1), then the same draws.
-        oracle.c_srand(1)
+        # the CLI is a fresh process: the library's copy of the reference's never-seeded rand() stream, nothing drawn before
+        # initial_guess -- the reference's own subsets (the mirror class's default up to 65 536 matches).  Same state here.
+        api.reference_rand_seed(1)
         e, t, ncand = p.initial_guess_reference(80, 0.25)
     assert ncand > 40
     rot0, tran0 = -e, t

@@ -132,7 +132,7 @@ def test_initial_guess_from_the_reference_subsets(oracle, n, store, monkeypatch)
     x1, x2 = (c.x1, c.x2) if store == api.STORE_F64 else (c.x1.astype(np.float32).astype(np.float64),
                                                           c.x2.astype(np.float32).astype(np.float64))
     subsets = oracle.reference_trial_subsets(n, 80, reseed=True)
-    oracle.c_srand(1)
+    api.reference_rand_seed(1)
     assert np.array_equal(api.reference_trial_subsets(n, 80, 0.25), subsets)
     e_ref, t_ref, nc_ref = _recipe_on_subsets(x1, x2, subsets)
     with api.Problem(0) as p:
@@ -141,12 +141,12 @@ def test_initial_guess_from_the_reference_subsets(oracle, n, store, monkeypatch)
         ref = subset_moments(x1, x2, subsets)
         assert np.abs(mom - ref).max() <= 1e-12 * np.abs(ref).max()
         assert np.array_equal(mom, p.epipolar_subset_moments(subsets))              # fixed fold order
-        oracle.c_srand(1)
+        api.reference_rand_seed(1)
         e, t, nc = p.initial_guess_reference(80, 0.25)
-        after = oracle.c_rand()
+        after = api.reference_rand_next()
         # SBA_GUESS_SAMPLING=reference routes the seeded entry point to the same path
         monkeypatch.setenv("SBA_GUESS_SAMPLING", "reference")
-        oracle.c_srand(1)
+        api.reference_rand_seed(1)
         e2, t2, nc2 = p.initial_guess(80, 0.25, 12345)
         monkeypatch.delenv("SBA_GUESS_SAMPLING")
         assert np.array_equal(e, e2) and np.array_equal(t, t2) and nc == nc2

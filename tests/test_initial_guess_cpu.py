@@ -256,28 +256,52 @@ def test_glibc_rand_stream_is_the_one_the_reference_runs_on(oracle):
     assert [oracle.c_rand() for _ in range(5)] == [1804289383, 846930886, 1681692777, 1714636915, 1957747793]
 
 
+@pytest.mark.parametrize("seed", [1, 0, 2, 12345, 2**31 - 1, 2**32 - 1])
+def test_library_copy_of_glibc_rand_equals_the_real_one(oracle, seed):
+    """The product draws the reference's subsets from its OWN copy of glibc's generator (csrc/sba_epipolar.hpp: GlibcRand) --
+    a process that has initialised HIP no longer owns rand() (libhsa-runtime64 imports srand and rand).  The copy must be
+    the real thing: 100 000 consecutive values equal to the C library's rand() for several seeds, seed 1 being the
+    never-seeded state the reference runs in."""
+    oracle.c_srand(seed)
+    api.reference_rand_seed(seed)
+    real = [oracle.c_rand() for _ in range(100_000)]
+    mine = [api.reference_rand_next() for _ in range(100_000)]
+    assert real == mine
+
+
 @pytest.mark.parametrize("n", [4, 5, 40, 333, 2048])
 def test_reference_subsets_equal_libstdcxx_random_shuffle(oracle, n):
-    """Product (hand-written loop on std::rand(), csrc/sba_epipolar.hpp) == the oracle's call of the REAL libstdc++
-    std::random_shuffle -- the function the reference itself calls (spherical_bundle_adjuster.hpp:209) -- element for
-    element over all 80 trials, from the same rand() state; and both consume the same number of draws."""
+    """Product (hand-written loop over its copy of glibc's rand(), csrc/sba_epipolar.hpp) == the oracle's call of the REAL
+    libstdc++ std::random_shuffle on the REAL rand() -- the function the reference itself calls
+    (spherical_bundle_adjuster.hpp:209) -- element for element over all 80 trials, from the same stream state; and both
+    consume the same number of draws."""
     ref = oracle.reference_trial_subsets(n, 80, reseed=True)
     after_ref = oracle.c_rand()
-    oracle.c_srand(1)
+    api.reference_rand_seed(1)
     got = api.reference_trial_subsets(n, 80, 0.25)
-    after_got = oracle.c_rand()
+    after_got = api.reference_rand_next()
     assert ref.shape == got.shape == (80, int(n * 0.25)) and np.array_equal(ref, got) and after_ref == after_got
     for row in got:                                   # each a prefix of a permutation of 0..n-1
         assert len(set(row.tolist())) == len(row) and (row >= 0).all() and (row < n).all()
     if n >= 40:
         assert len({tuple(r) for r in got.tolist()}) == 80        # a FRESH permutation per trial
-    # mid-stream (a matcher -- FLANN's kd-trees call rand() -- ran first): still the same lists from the same state
-    oracle.c_srand(1)
-    burn = [oracle.c_rand() for _ in range(1234)]
+    # the stream runs on from call to call (a second image pair in the same process): still the same lists as the real thing
     ref2 = oracle.reference_trial_subsets(n, 3, reseed=False)
+    got2 = api.reference_trial_subsets(n, 3, 0.25)
+    assert np.array_equal(ref2, got2) and (n < 40 or not np.array_equal(ref2, ref[:3]))
+
+
+def test_reference_subsets_from_the_process_rand_on_request(oracle, monkeypatch):
+    """SBA_GUESS_RAND=libc: draw from the process's own rand() instead -- the matcher's draws (FLANN's kd-trees call rand())
+    then count exactly as in the reference's process."""
+    monkeypatch.setenv("SBA_GUESS_RAND", "libc")
+    oracle.c_srand(1)
+    burn = [oracle.c_rand() for _ in range(1234)]                       # "the matcher"
+    ref = oracle.reference_trial_subsets(333, 3, reseed=False)
     oracle.c_srand(1)
     assert [oracle.c_rand() for _ in range(1234)] == burn
-    assert np.array_equal(ref2, api.reference_trial_subsets(n, 3, 0.25)) and (n < 40 or not np.array_equal(ref2, ref[:3]))
+    assert np.array_equal(api.reference_trial_subsets(333, 3, 0.25), ref)
+    assert not np.array_equal(ref, oracle.reference_trial_subsets(333, 3, reseed=True))
 
 
 def _recipe_on_subsets(x1, x2, subsets):
