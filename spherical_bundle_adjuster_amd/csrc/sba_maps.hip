@@ -227,7 +227,13 @@ constexpr int kTileW = 32, kTileH = 32, kTilePx = kTileW * kTileH, kTileLanePx =
 // 6 / 8 / 12 / 16 / 24 KiB = 7.35 / 6.64-6.95 / 6.82-7.10 / 8.18 / 8.19 us per frame (31 / 72 / 89 / 94 / 100 % of the
 // tiles staged): a larger budget stages more tiles but leaves fewer blocks per CU.
 constexpr int kTileLdsBudget = 8192;
-struct TileHdr { unsigned chunks, pad; };     // chunks == 0: not staged; the tile's list is chunk_list[tile * list_stride ...]
+// A work item of the tiled gather: a 32 x 32 output tile (4 pixels per lane), or -- where a 32 x 32 tile's chunk list is
+// over budget: the pole centres, where every pixel sits in its own source chunk -- one of its four 16 x 16 quarters
+// (1 pixel per lane; at most 2 x 256 chunks = 8 KiB, so a quarter always fits the budget).  chunks == 0: not staged
+// (only a list that reaches past the end of the frame), the pixels then come straight from global memory.  The item's
+// list is chunk_list[item * list_stride ...], its LDS offsets lds_offset[item * kTilePx ...].
+struct TileHdr { unsigned chunks; unsigned short x0, y0; unsigned short shift, pad; };    // shift = log2(edge): 5 or 4
+static_assert(sizeof(TileHdr) == 12, "TileHdr layout");
 
 template <bool PACK>
 __global__ __launch_bounds__(256) void gather_tiled_kernel(const int* __restrict__ table, const TileHdr* __restrict__ hdr,
@@ -255,14 +261,14 @@ __global__ __launch_bounds__(256) void gather_tiled_kernel(const int* __restrict
 #pragma unroll
   for (int m = 0; m < 2; ++m) entry[m] = t + 256u * m < list_stride ? list[t + 256 * m] : 0u;
   const TileHdr h = hdr[tile];
-  const int ty = static_cast<int>(tile) / tiles_x, tx = static_cast<int>(tile) - ty * tiles_x;
   const int f0 = static_cast<int>(group) * frames_per_block, f1 = min(batch, f0 + frames_per_block);
+  const int edge_mask = (1 << h.shift) - 1, item_px = 1 << (2 * h.shift);       // 1024 or 256 pixels
   size_t g[kTileLanePx];
   bool active[kTileLanePx];
 #pragma unroll
   for (int m = 0; m < kTileLanePx; ++m) {
-    const int q = t + 256 * m, orow = ty * kTileH + q / kTileW, ocol = tx * kTileW + q % kTileW;
-    active[m] = ocol < out_w && orow < out_h;
+    const int q = t + 256 * m, orow = h.y0 + (q >> h.shift), ocol = h.x0 + (q & edge_mask);
+    active[m] = q < item_px && ocol < out_w && orow < out_h;
     g[m] = static_cast<size_t>(orow) * out_w + ocol;
   }
   auto store = [&](uint8_t* d, uint32_t v, int m) {
@@ -426,7 +432,8 @@ struct Table {
   size_t host_decided = 0;    // outputs finished on the host when the table was built
   // tiled form of the same map (gather_tiled_kernel); tile_hdr == nullptr: not available
   int out_w = 0, out_h = 0, tiles_x = 0, lds_per_frame = 0;
-  unsigned ntiles = 0, staged_tiles = 0, list_stride = 0;
+  unsigned ntiles = 0, staged_tiles = 0, list_stride = 0;   // 32 x 32 tiles of the output; how many are staged through LDS entirely
+  unsigned nitems = 0;                                       // work items: staged 32 x 32 tiles + the 16 x 16 quarters of the others
   TileHdr* tile_hdr = nullptr;
   unsigned* chunk_list = nullptr;
   unsigned short* lds_offset = nullptr;
@@ -455,17 +462,21 @@ int build_tiles(Table* t, hipStream_t stream) {
   }
   const int tiles_x = (out_w + kTileW - 1) / kTileW, tiles_y = (out_h + kTileH - 1) / kTileH;
   const size_t ntiles = static_cast<size_t>(tiles_x) * tiles_y;
-  std::vector<TileHdr> hdr(ntiles, TileHdr{0u, 0u});
-  const size_t list_stride = budget / 16;              // entries per tile: fixed, so that a block finds its list without the header
-  std::vector<unsigned> chunk_list(ntiles * list_stride, 0u);
-  std::vector<unsigned short> lds_offset(ntiles * kTilePx, 0xffff);
+  const size_t list_stride = budget / 16;              // entries per item: fixed, so that a block finds its list without the header
+  // SBA_GATHER_SUBTILES=0 (A/B measurements): over-budget tiles stay whole and gather from global memory, as in round 2
+  const bool subtiles = [] { const char* e = std::getenv("SBA_GATHER_SUBTILES"); return !(e && e[0] == '0'); }();
+  std::vector<TileHdr> hdr;
+  std::vector<unsigned> chunk_list;
+  std::vector<unsigned short> lds_offset;
   std::vector<unsigned> ids;
-  unsigned staged = 0, lds_max = 0;
-  for (size_t tile = 0; tile < ntiles; ++tile) {
-    const int ty = static_cast<int>(tile / tiles_x), tx = static_cast<int>(tile % tiles_x);
+  unsigned lds_max = 0;
+  // One work item: the square of edge 2^shift at (x0, y0).  Returns false -- and appends nothing -- when its chunk list
+  // is over budget and `must` is not set; with `must` an over-budget (or past-the-end) item is appended un-staged.
+  auto add_item = [&](int x0, int y0, int shift, bool must) -> bool {
+    const int edge = 1 << shift, px = edge * edge;
     ids.clear();
-    for (int q = 0; q < kTilePx; ++q) {
-      const int orow = ty * kTileH + q / kTileW, ocol = tx * kTileW + q % kTileW;
+    for (int q = 0; q < px; ++q) {
+      const int orow = y0 + (q >> shift), ocol = x0 + (q & (edge - 1));
       if (orow >= out_h || ocol >= out_w) continue;
       const int idx = table[static_cast<size_t>(orow) * out_w + ocol];
       if (idx < 0) continue;
@@ -477,24 +488,45 @@ int build_tiles(Table* t, hipStream_t stream) {
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
     // stage unless the list is over budget, empty (nothing to read), or its last chunk reaches past the frame (the last
     // frame of a batch must not be read beyond its end)
-    if (ids.empty() || ids.size() * 16 > budget || (static_cast<size_t>(ids.back()) + 1) * 16 > frame_bytes) continue;
-    hdr[tile] = TileHdr{static_cast<unsigned>(ids.size()), 0u};
-    for (size_t k = 0; k < ids.size(); ++k) chunk_list[tile * list_stride + k] = ids[k] * 16u;
-    for (int q = 0; q < kTilePx; ++q) {
-      const int orow = ty * kTileH + q / kTileW, ocol = tx * kTileW + q % kTileW;
+    const bool stage = !ids.empty() && ids.size() * 16 <= budget && (static_cast<size_t>(ids.back()) + 1) * 16 <= frame_bytes;
+    if (!stage && !must && ids.size() * 16 > budget) return false;
+    const size_t item = hdr.size();
+    hdr.push_back(TileHdr{stage ? static_cast<unsigned>(ids.size()) : 0u, static_cast<unsigned short>(x0), static_cast<unsigned short>(y0),
+                          static_cast<unsigned short>(shift), 0});
+    chunk_list.resize((item + 1) * list_stride, 0u);
+    lds_offset.resize((item + 1) * kTilePx, 0xffff);
+    if (!stage) return true;
+    for (size_t k = 0; k < ids.size(); ++k) chunk_list[item * list_stride + k] = ids[k] * 16u;
+    for (int q = 0; q < px; ++q) {
+      const int orow = y0 + (q >> shift), ocol = x0 + (q & (edge - 1));
       if (orow >= out_h || ocol >= out_w) continue;
       const int idx = table[static_cast<size_t>(orow) * out_w + ocol];
       if (idx < 0) continue;
       const size_t o = static_cast<size_t>(idx) * 3;
       const size_t rank = static_cast<size_t>(std::lower_bound(ids.begin(), ids.end(), static_cast<unsigned>(o >> 4)) - ids.begin());
-      lds_offset[tile * kTilePx + q] = static_cast<unsigned short>(rank * 16 + (o & 15));
+      lds_offset[item * kTilePx + q] = static_cast<unsigned short>(rank * 16 + (o & 15));
     }
-    ++staged;
     lds_max = std::max<unsigned>(lds_max, static_cast<unsigned>(ids.size() * 16));
+    return true;
+  };
+  if (out_w > 0xffff || out_h > 0xffff) return SBA_OK;           // item origins are 16-bit: such outputs keep the untiled kernel
+  unsigned staged = 0;
+  for (size_t tile = 0; tile < ntiles; ++tile) {
+    const int x0 = static_cast<int>(tile % tiles_x) * kTileW, y0 = static_cast<int>(tile / tiles_x) * kTileH;
+    const size_t first = hdr.size();
+    if (!add_item(x0, y0, 5, !subtiles))
+      for (int sub = 0; sub < 4; ++sub)      // over budget: its four 16 x 16 quarters, each at most 2 x 256 chunks
+        if (x0 + (sub & 1) * 16 < out_w && y0 + (sub >> 1) * 16 < out_h) (void)add_item(x0 + (sub & 1) * 16, y0 + (sub >> 1) * 16, 4, true);
+    bool all = true;
+    for (size_t k = first; k < hdr.size(); ++k) all = all && hdr[k].chunks > 0;
+    if (all) ++staged;
   }
+  unsigned staged_items = 0;
+  for (const TileHdr& h : hdr) staged_items += h.chunks > 0 ? 1u : 0u;
   t->tiles_x = tiles_x; t->ntiles = static_cast<unsigned>(ntiles); t->staged_tiles = staged; t->lds_per_frame = static_cast<int>(lds_max);
+  t->nitems = static_cast<unsigned>(hdr.size());
   t->list_stride = static_cast<unsigned>(list_stride);
-  if (staged == 0) return SBA_OK;
+  if (staged_items == 0) return SBA_OK;
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->tile_hdr), hdr.size() * sizeof(TileHdr)));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->chunk_list), std::max<size_t>(chunk_list.size(), 1) * sizeof(unsigned)));
   SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&t->lds_offset), lds_offset.size() * sizeof(unsigned short)));
@@ -605,18 +637,18 @@ int launch_gather(const Table& t, const uint8_t* src, int src_pixels, int batch,
   // keeps the pixel-per-lane kernel (A/B measurements).
   const char* tiled_env = std::getenv("SBA_GATHER_TILED");
   const bool aligned = reinterpret_cast<uintptr_t>(src) % 16 == 0 && (batch == 1 || src_stride % 16 == 0);
-  if (t.tile_hdr && t.staged_tiles > 0 && aligned && !(tiled_env && tiled_env[0] == '0')) {
-    const unsigned long long items = static_cast<unsigned long long>(t.ntiles) * gy;
+  if (t.tile_hdr && t.nitems > 0 && aligned && !(tiled_env && tiled_env[0] == '0')) {
+    const unsigned long long items = static_cast<unsigned long long>(t.nitems) * gy;
     if (items > 0x7fffff00ull) return set_error(SBA_ERR_INVALID_ARG, "batch of %d frames is too large for one launch", batch);
     const unsigned tgrid = static_cast<unsigned>((items + 7ull) / 8ull * 8ull);
     const size_t lds = static_cast<size_t>(t.lds_per_frame) * fpb;
     if (t.out_w % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 4 == 0 && out_stride % 4 == 0)
       hipLaunchKernelGGL((gather_tiled_kernel<true>), dim3(tgrid), dim3(256), lds, stream, t.dev, t.tile_hdr, t.chunk_list, t.list_stride, t.lds_offset,
-                         t.ntiles, t.tiles_x, t.out_w, t.out_h, src, src_stride, out, out_stride, batch, fpb, t.lds_per_frame,
+                         t.nitems, t.tiles_x, t.out_w, t.out_h, src, src_stride, out, out_stride, batch, fpb, t.lds_per_frame,
                          static_cast<unsigned>(items), xcd_aware);
     else
       hipLaunchKernelGGL((gather_tiled_kernel<false>), dim3(tgrid), dim3(256), lds, stream, t.dev, t.tile_hdr, t.chunk_list, t.list_stride, t.lds_offset,
-                         t.ntiles, t.tiles_x, t.out_w, t.out_h, src, src_stride, out, out_stride, batch, fpb, t.lds_per_frame,
+                         t.nitems, t.tiles_x, t.out_w, t.out_h, src, src_stride, out, out_stride, batch, fpb, t.lds_per_frame,
                          static_cast<unsigned>(items), xcd_aware);
     SBA_TRY_HIP(hipGetLastError());
     return SBA_OK;

@@ -378,8 +378,10 @@ def test_gather_paths_agree_and_tiles_are_staged(oracle, H, W, S, F):
     tiles, staged, lds = C.c_int(0), C.c_int(0), C.c_int(0)
     assert lib.sba_map_table_tiles(0, 0, S, H, W, C.byref(tiles), C.byref(staged), C.byref(lds)) == 0
     assert tiles.value == -(-S // 32) * -(-6 * S // 32) and 0 < staged.value <= tiles.value and 0 < lds.value <= 8192
-    if (H, W) == (1920, 3840):
-        assert staged.value >= 0.6 * tiles.value           # the C5 geometry: most tiles fit the LDS budget
+    # round 3: a 32 x 32 tile whose chunk list is over the LDS budget is handled as its four 16 x 16 quarters (at most
+    # 2 x 256 chunks each: they always fit), so EVERY tile is staged -- except one whose last chunk would reach past the
+    # end of the frame (the bottom-right source pixel; at most a few tiles)
+    assert staged.value >= tiles.value - 4, (staged.value, tiles.value)
     os.environ["SBA_GATHER_TILED"] = "0"
     try:
         assert np.array_equal(run(src), want)
