@@ -484,10 +484,11 @@ class GlibcRand {
     for (int i = 0; i < 310; ++i) (void)next();
   }
   int next() {                                                       // what rand() returns: 0 .. RAND_MAX = 2^31 - 1
-    r_[f_] += r_[b_];
-    const uint32_t v = r_[f_] >> 1;
-    f_ = (f_ + 1) % 31; b_ = (b_ + 1) % 31;
-    return static_cast<int>(v);
+    const uint32_t sum = r_[f_] + r_[b_];
+    r_[f_] = sum;
+    f_ = f_ == 30 ? 0 : f_ + 1;
+    b_ = b_ == 30 ? 0 : b_ + 1;
+    return static_cast<int>(sum >> 1);
   }
 
  private:
@@ -505,9 +506,11 @@ inline void reference_trial_subsets(int n, int trials, double fraction, int* out
   std::vector<int> perm(static_cast<size_t>(std::max(n, 0)));
   for (int trial = 0; trial < trials; ++trial) {
     for (int i = 0; i < n; ++i) perm[i] = i;                                  // std::iota
+    int* a = perm.data();
     for (int i = 1; i < n; ++i) {                                             // std::random_shuffle, libstdc++
-      const int j = next_rand() % (i + 1);
-      if (i != j) std::swap(perm[i], perm[j]);
+      const unsigned j = static_cast<unsigned>(next_rand()) % static_cast<unsigned>(i + 1);   // rand() >= 0: same as the int %
+      const int vi = a[i], vj = a[j];       // i == j: swapping an element with itself is the identity
+      a[i] = vj; a[j] = vi;
     }
     for (int k = 0; k < sample_n; ++k) out[static_cast<size_t>(trial) * sample_n + k] = perm[k];
   }

@@ -29,6 +29,8 @@ struct sba_problem {
   int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
   double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
   size_t epi_scratch_elems = 0;
+  void* subset_scratch = nullptr;  // reference sampling: [trials][45] moments, then the [trials][m] index lists; kept across calls
+  size_t subset_scratch_bytes = 0;
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
   int last_mode = 0;
 
@@ -70,8 +72,12 @@ struct sba_problem {
   sba::ResidentRecord* res_rec = nullptr;
   sba::ResidentRecord* res_rec_dev = nullptr;
   unsigned long long res_cmd_seq = 0;     // sequence number of the last command written
-  size_t resident_max_n = 8192;           // SBA_RESIDENT_MAX_N: largest problem the solve stages drive through a resident
-                                          // single-block kernel (0 = never); above it every sweep / pass is a launch
+  // Largest problem the LM stages / the d-only stage drive through a resident single-block kernel; above it every sweep /
+  // pass is a launch.  Measured cross-over on MI355X (profiles/r03_c1_pipeline.md): one block sweeps 4 096 matches in less
+  // time than two launches cost, but the d-only pass is arithmetic-heavy (4 exp + a reciprocal per match) and one CU falls
+  // behind the 4-16 CUs a launch spreads it over from ~3 000 matches on.  SBA_RESIDENT_MAX_N overrides both (0 = never).
+  size_t resident_max_n = 4096;
+  size_t resident_max_n_depth = 2560;
   double resident_idle_s = 0.25;          // SBA_RESIDENT_IDLE_S: a resident kernel ends itself after this long without a command
 
   sba_allreduce_fn hook = nullptr;
@@ -107,7 +113,7 @@ inline bool is_collective(const sba_problem* p) { return p->comm != nullptr || p
 // sba_resident.cpp -- one resident kernel serving one solve stage of a small, unsharded problem.  start_*() launches it,
 // call() sends a command and waits for its answer (restarting a kernel that ended itself: idle time-out, trip limit),
 // end() sends QUIT and waits, bounded, for the stream to drain; the destructor ends a session that is still open.
-bool resident_eligible(const sba_problem* p);
+bool resident_eligible(const sba_problem* p, bool depth_stage);
 class ResidentSession {
  public:
   explicit ResidentSession(sba_problem* p) : p_(p) {}

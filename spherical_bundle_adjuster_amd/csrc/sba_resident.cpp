@@ -8,8 +8,9 @@
 namespace sba {
 namespace shim {
 
-bool resident_eligible(const sba_problem* p) {
-  return p->res_rec != nullptr && p->publish && !is_collective(p) && p->uploaded && p->n > 0 && p->n <= p->resident_max_n;
+bool resident_eligible(const sba_problem* p, bool depth_stage) {
+  return p->res_rec != nullptr && p->publish && !is_collective(p) && p->uploaded && p->n > 0 &&
+         p->n <= (depth_stage ? p->resident_max_n_depth : p->resident_max_n);
 }
 
 int ResidentSession::launch() {

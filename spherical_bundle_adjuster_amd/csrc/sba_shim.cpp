@@ -438,7 +438,10 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
                             hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(p->res_rec, 0, sizeof(sba::ResidentRecord));
   SBA_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->res_rec_dev), p->res_rec, 0));
-  if (const char* env = std::getenv("SBA_RESIDENT_MAX_N")) { const long v = std::atol(env); if (v >= 0) p->resident_max_n = static_cast<size_t>(v); }
+  if (const char* env = std::getenv("SBA_RESIDENT_MAX_N")) {
+    const long v = std::atol(env);
+    if (v >= 0) p->resident_max_n = p->resident_max_n_depth = static_cast<size_t>(v);
+  }
   if (const char* env = std::getenv("SBA_RESIDENT_IDLE_S")) { const double v = std::atof(env); if (v > 0.0 && v <= 10.0) p->resident_idle_s = v; }
   guard.p = nullptr;     // hand over
   *out = p;
@@ -467,6 +470,7 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->ticket) (void)hipFree(p->ticket);
   if (p->peer_sticky) (void)hipFree(p->peer_sticky);
   if (p->epi_scratch) (void)hipFree(p->epi_scratch);
+  if (p->subset_scratch) (void)hipFree(p->subset_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->res_rec) (void)hipHostFree(p->res_rec);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -749,7 +753,7 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
   // stage -- the host LM below is unchanged, only the evaluator talks to a kernel that is already running instead of
   // launching two per iteration (sba_resident.hpp).  SBA_RESIDENT_MAX_N=0 keeps the launch-per-sweep path.
   sba::shim::ResidentSession session(p);
-  if (sba::shim::resident_eligible(p)) {
+  if (sba::shim::resident_eligible(p, false)) {
     SBA_HIP_TRY(hipSetDevice(p->device));
     rc = session.start_sweep(mode, depth_mode, o.huber_delta > 0.0);
     if (rc) return rc;

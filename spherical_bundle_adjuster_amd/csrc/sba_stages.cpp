@@ -126,7 +126,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   // path: `flip` says that the work planes currently hold the depths and the problem's planes take the candidates.
   sba::shim::ResidentSession session(p);
   bool flip = false;
-  if (sba::shim::resident_eligible(p)) {
+  if (sba::shim::resident_eligible(p, true)) {
     const int rc = session.start_depth(p->dplane[0], p->dplane[1], c1, c2, sc1, sc2);
     if (rc) return rc;
   }
@@ -280,16 +280,22 @@ int sba_problem_epipolar_subset_moments(sba_problem* p, const int* indices, int 
   if (trials == 0) return SBA_OK;
   if (sample_n == 0) { std::memset(moments, 0, msz * sizeof(double)); return SBA_OK; }
   SBA_TRY_HIP(hipSetDevice(p->device));
-  sba::DeviceBuffer idx_dev(&p->poisoned), mom_dev(&p->poisoned);
-  SBA_TRY_HIP(idx_dev.alloc(count * sizeof(int)));
-  SBA_TRY_HIP(mom_dev.alloc(msz * sizeof(double)));
-  SBA_TRY_HIP(hipMemcpyAsync(idx_dev.ptr, indices, count * sizeof(int), hipMemcpyHostToDevice, p->stream));
+  // scratch lives in the handle (a hipMalloc / hipFree pair per call costs more than the pass): moments first, then the lists
+  const size_t need = msz * sizeof(double) + count * sizeof(int);
+  if (p->subset_scratch_bytes < need) {
+    if (p->subset_scratch) SBA_TRY_HIP(hipFree(p->subset_scratch));
+    p->subset_scratch = nullptr; p->subset_scratch_bytes = 0;
+    SBA_TRY_HIP(hipMalloc(&p->subset_scratch, need));
+    p->subset_scratch_bytes = need;
+  }
+  double* mom_dev_ptr = static_cast<double*>(p->subset_scratch);
+  int* idx_dev_ptr = reinterpret_cast<int*>(mom_dev_ptr + msz);
+  SBA_TRY_HIP(hipMemcpyAsync(idx_dev_ptr, indices, count * sizeof(int), hipMemcpyHostToDevice, p->stream));
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
   pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
-  SBA_TRY_HIP(sba::launch_epipolar_subset_moments(p->store, pl, p->n, idx_dev.as<int>(), trials, sample_n, mom_dev.as<double>(),
-                                                  p->stream));
-  SBA_TRY_HIP(hipMemcpyAsync(moments, mom_dev.ptr, msz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  SBA_TRY_HIP(sba::launch_epipolar_subset_moments(p->store, pl, p->n, idx_dev_ptr, trials, sample_n, mom_dev_ptr, p->stream));
+  SBA_TRY_HIP(hipMemcpyAsync(moments, mom_dev_ptr, msz * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   { const int _rc = sba::stream_wait(p->stream, "subset moments", &p->poisoned); if (_rc) return _rc; }
   return SBA_OK;
 }

@@ -274,7 +274,7 @@ int main() {
     sba_problem* p = nullptr;
     REQUIRE(sba_problem_create(&p, 0, nullptr) == SBA_OK);
     REQUIRE(sba_problem_upload(p, x.data(), x.data(), d12.data(), n, SBA_STORE_F64) == SBA_OK);
-    REQUIRE(sba::shim::resident_eligible(p));
+    REQUIRE(sba::shim::resident_eligible(p, false) && sba::shim::resident_eligible(p, true));
     p->resident_idle_s = 0.05;
     const int launched0 = sba::g_kernels_launched.load();
     double payload[44], got[24];

@@ -114,7 +114,7 @@ def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
 @pytest.mark.parametrize("n,store", [(7, api.STORE_F64), (63, api.STORE_F64), (2048, api.STORE_F64), (2049, api.STORE_F32),
                                      (8192, api.STORE_F64)])
 def test_resident_evaluator_equals_the_launch_path(oracle, n, store, monkeypatch):
-    """Small problems (<= SBA_RESIDENT_MAX_N = 8192 matches: BASELINE config C1, the reference's real workload) are solved
+    """Small problems (up to 4 096 matches, 2 560 for the d-only stage: BASELINE config C1, the reference's real workload) are solved
     with ONE resident single-block kernel per stage that the host LM / d-only state machine commands through mapped
     memory (csrc/sba_resident.hpp) instead of two launches per sweep.  Same state machines, same per-match arithmetic;
     only the fold order of the sums differs (one block instead of a grid + finalize kernel): all three stages must
@@ -123,11 +123,8 @@ def test_resident_evaluator_equals_the_launch_path(oracle, n, store, monkeypatch
     c = synthetic.full_rt(n, seed=4200 + n, sigma=5e-4)
     start = np.full((n, 2), 3.0)
     res = {}
-    for name, max_n in (("resident", None), ("launch", "0")):
-        if max_n is None:
-            monkeypatch.delenv("SBA_RESIDENT_MAX_N", raising=False)
-        else:
-            monkeypatch.setenv("SBA_RESIDENT_MAX_N", max_n)
+    for name, max_n in (("resident", "100000"), ("launch", "0")):     # force either path at every size (defaults: 4 096 / 2 560)
+        monkeypatch.setenv("SBA_RESIDENT_MAX_N", max_n)
         with api.Problem(0) as p:
             p.upload(c.x1, c.x2, start, store=store)
             d, sd = p.solve_depths(c.rot_init, c.tran_init)
