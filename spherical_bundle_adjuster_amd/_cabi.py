@@ -169,7 +169,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    # SBA_LIBRARY_PATH: a differently built libsba_hip.so (tools' A/B measurements of build variants only)
+    p = Path(path) if path else Path(os.environ.get("SBA_LIBRARY_PATH", LIB_PATH))
     if not p.exists():
         raise LibraryNotBuilt(
             f"{p} not found: build it with `make -C {PKG_DIR / 'csrc'}` or "

@@ -286,14 +286,15 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(Planes pl, const Pai
   if (tid < 24) {
     const double v = raw_s[tid];
     packs[static_cast<size_t>(pair) * 24 + tid] = v;
-    if (packs_host) packs_host[static_cast<size_t>(pair) * 24 + tid] = v;
+    if (packs_host) host_store(packs_host + static_cast<size_t>(pair) * 24 + tid, v);
   }
   if (!packs_host) return;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  host_release();
   if (tid == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if !SBA_PUBLISH_WRITE_THROUGH
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(packs_host + static_cast<size_t>(gridDim.x) * 24), seq,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

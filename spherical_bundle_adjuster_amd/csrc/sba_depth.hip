@@ -293,11 +293,10 @@ __global__ __launch_bounds__(64 * DEPTH_OUT_COUNT) void depth_finalize_kernel(co
   }
   if (threadIdx.x < DEPTH_OUT_COUNT) {
     out[threadIdx.x] = res[threadIdx.x];
-    if (host_out) host_out[threadIdx.x] = res[threadIdx.x];
+    if (host_out) host_store(host_out + threadIdx.x, res[threadIdx.x]);
   }
   if (host_out && threadIdx.x < 64) {     // wave 0 holds all nine host stores
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    host_release();
     if (threadIdx.x == 0)
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + 24), seq, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);

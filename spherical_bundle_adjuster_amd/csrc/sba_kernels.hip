@@ -28,6 +28,7 @@
 // This file: the single-problem sweep kernel, the final reduction / peer exchange / host hand-over kernels and their
 // launchers.  Shared device core: sba_sweep_core.hpp; batched kernels: sba_batch_kernels.hip; upload / key-point / cubemap
 // kernels: sba_side.hip.
+#include "sba_publish.hpp"
 #include "sba_sweep_core.hpp"
 
 namespace sba {
@@ -248,10 +249,9 @@ __device__ __forceinline__ double peer_exchange_wave(double v, const PeerInboxes
 // memory, word 25 = error flag, system-scope release, then the sequence number the host polls.
 __device__ __forceinline__ void publish_wave(double v, double* __restrict__ pack_host, unsigned long long host_seq,
                                              bool ok, int lane) {
-  if (lane < 24) pack_host[lane] = v;
-  if (lane == 0) reinterpret_cast<unsigned long long*>(pack_host)[25] = ok ? 0ull : 1ull;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < 24) host_store(pack_host + lane, v);
+  if (lane == 0) host_store(reinterpret_cast<unsigned long long*>(pack_host) + 25, ok ? 0ull : 1ull);
+  host_release();
   if (lane == 0)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(pack_host + 24), host_seq, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);

@@ -23,6 +23,9 @@
 // kernel that ended on its own is restarted transparently by the host on the next command.
 #pragma once
 #include "sba_device.hpp"
+#if defined(__HIPCC__)
+#include "sba_publish.hpp"
+#endif
 
 namespace sba {
 
@@ -90,9 +93,8 @@ __device__ __forceinline__ int resident_wait_command(const ResidentRecord* __res
 __device__ __forceinline__ void resident_publish(double* __restrict__ host_pack, const double* __restrict__ res_s, int count,
                                                  unsigned long long seq) {
   const int lane = threadIdx.x & 63;
-  if (lane < count) host_pack[lane] = res_s[lane];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < count) host_store(host_pack + lane, res_s[lane]);
+  host_release();
   if (lane == 0)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_pack + 24), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
