@@ -210,3 +210,59 @@ def test_committed_depth_fixture_cases_and_line_search(oracle):
         _, s, _ = oracle.depth_solve(cs.x1, cs.x2, cs.rot_init, cs.tran_init, np.full((n, 2), d0), lam=lam, c=c)
         seen[(n, seed)] = s.num_line_search_steps
     assert seen[(500, 6)] == 1 and seen[(400, 9)] == 1 and seen[(300, 11)] == 1 and seen[(300, 12)] == 0
+
+
+# ---- hand-derived cases: pinned by pencil and paper, not by another restatement ----------------------------------
+def test_hand_derived_cubic_interpolation_step(oracle):
+    """phi(a) = a^3 + a^2 - a + 3: phi(0) = 3, phi'(0) = -1; first trial a = 1: phi = 4, phi' = 4.  The interpolant through
+    value and slope at 0 and 1 is that very cubic (4 conditions, degree 3); phi' = 3a^2 + 2a - 1 = (3a - 1)(a + 1), so its
+    minimiser is a = 1/3 EXACTLY, inside Ceres' bracket [1e-3, 0.6].  The full step fails Armijo (4 > 3 - 1e-4), the next
+    trial must be 1/3, where phi = 3 - 5/27 passes (3 - 5/27 <= 3 - 1e-4 / 3): one contraction, step size 1/3."""
+    samples = [(0.0, 3.0, -1.0), (1.0, 4.0, 4.0)]
+    assert abs(product_hermite_argmin(samples, 1e-3, 0.6) - 1.0 / 3.0) <= 1e-14
+    poly = oracle.interpolating_polynomial(samples)
+    assert np.abs(poly - np.array([1.0, 1.0, -1.0, 3.0])).max() <= 1e-13
+    assert abs(oracle.minimize_polynomial(poly, 1e-3, 0.6)[0] - 1.0 / 3.0) <= 1e-12
+    phi = lambda a: (a**3 + a**2 - a + 3.0, 3 * a**2 + 2 * a - 1.0)
+    for search in (product_armijo, oracle.armijo):
+        trials = []
+
+        def rec(a):
+            trials.append(a)
+            return phi(a)
+        ok, step, contractions = search(rec, 3.0, -1.0)
+        assert ok and contractions == 1 and abs(step - 1.0 / 3.0) <= 1e-12, (search.__name__, ok, step, contractions)
+        assert trials[0] == 1.0 and abs(trials[1] - 1.0 / 3.0) <= 1e-12 and len(trials) == 2
+    # the bracket clamps: phi(a) = (a - 0.9)^2 has its interpolated minimiser at 0.9 > 0.6 -> the next trial is 0.6 exactly
+    assert product_hermite_argmin([(0.0, 0.81, -1.8), (1.0, 0.01, 0.2)], 1e-3, 0.6) == 0.6
+
+
+def test_hand_derived_bound_active_case_where_the_projection_changes_the_slope(oracle):
+    """One bounded parameter, d >= 0: d = 1, step delta = -4, cost f(d) = (d - 0.5)^2.  Ceres line-searches along the
+    PROJECTED path, phi(a) = f(P(1 - 4a)) with P(d) = max(d, 0), and feeds the interpolation the slope g(P(d + a delta)) . delta
+    -- the gradient at the projected point times the UN-projected direction (LineSearchFunction::Evaluate), not d phi / d a.
+      a = 0   : phi = 0.25, slope = 2 (1 - 0.5) (-4) = -4
+      a = 1   : P(-3) = 0, phi = 0.25 > 0.25 - 4e-4 -> rejected; slope fed = 2 (0 - 0.5) (-4) = +4 (the true d phi / d a is 0)
+    Cubic through (0, 0.25, -4), (1, 0.25, +4): 0.25 - 4a + 4a^2, minimiser a = 1/2 exactly -> second trial 0.5.
+      a = 0.5 : P(-1) = 0 again, phi = 0.25 -> rejected, slope fed = +4.
+    From then on the quintic through three samples decides; every later trial lies in Ceres' bracket of the trial before
+    it, and the accepted one satisfies Armijo on the projected path.  Product and oracle walk the same trials."""
+    def phi(a):
+        d = max(1.0 - 4.0 * a, 0.0)
+        return (d - 0.5) ** 2, 2.0 * (d - 0.5) * -4.0
+    walks = []
+    for search in (product_armijo, oracle.armijo):
+        trials = []
+
+        def rec(a):
+            trials.append(a)
+            return phi(a)
+        ok, step, contractions = search(rec, 0.25, -4.0)
+        assert ok and trials[0] == 1.0 and abs(trials[1] - 0.5) <= 1e-14, (search.__name__, trials)
+        for prev, cur in zip(trials[1:], trials[2:]):
+            assert 1e-3 * prev - 1e-15 <= cur <= 0.6 * prev + 1e-15
+        assert step == trials[-1] and contractions == len(trials) - 1
+        assert phi(step)[0] <= 0.25 + 1e-4 * step * -4.0                       # Armijo on the projected path
+        assert all(phi(a)[0] > 0.25 + 1e-4 * a * -4.0 for a in trials[:-1])    # ... and on no earlier trial
+        walks.append(trials)
+    assert len(walks[0]) == len(walks[1]) and np.abs(np.array(walks[0]) - np.array(walks[1])).max() <= 1e-9
