@@ -227,11 +227,11 @@ constexpr int kTileW = 32, kTileH = 32, kTilePx = kTileW * kTileH, kTileLanePx =
 // 6 / 8 / 12 / 16 / 24 KiB = 7.35 / 6.64-6.95 / 6.82-7.10 / 8.18 / 8.19 us per frame (31 / 72 / 89 / 94 / 100 % of the
 // tiles staged): a larger budget stages more tiles but leaves fewer blocks per CU.
 constexpr int kTileLdsBudget = 8192;
-// A work item of the tiled gather: a 32 x 32 output tile (4 pixels per lane), or -- where a 32 x 32 tile's chunk list is
-// over budget: the pole centres, where every pixel sits in its own source chunk -- one of its four 16 x 16 quarters
-// (1 pixel per lane; at most 2 x 256 chunks = 8 KiB, so a quarter always fits the budget).  chunks == 0: not staged
-// (only a list that reaches past the end of the frame), the pixels then come straight from global memory.  The item's
-// list is chunk_list[item * list_stride ...], its LDS offsets lds_offset[item * kTilePx ...].
+// A work item of the tiled gather: a 32 x 32 output tile (4 pixels per lane), or -- with SBA_GATHER_SUBTILES=1, where a
+// 32 x 32 tile's chunk list is over budget: the pole centres, where every pixel sits in its own source chunk -- one of its
+// four 16 x 16 quarters (1 pixel per lane; at most 2 x 256 chunks = 8 KiB, so a quarter always fits the budget).
+// chunks == 0: not staged (list over budget, or reaching past the end of the frame), the pixels then come straight from
+// global memory.  The item's list is chunk_list[item * list_stride ...], its LDS offsets lds_offset[item * kTilePx ...].
 struct TileHdr { unsigned chunks; unsigned short x0, y0; unsigned short shift, pad; };    // shift = log2(edge): 5 or 4
 static_assert(sizeof(TileHdr) == 12, "TileHdr layout");
 
@@ -463,8 +463,12 @@ int build_tiles(Table* t, hipStream_t stream) {
   const int tiles_x = (out_w + kTileW - 1) / kTileW, tiles_y = (out_h + kTileH - 1) / kTileH;
   const size_t ntiles = static_cast<size_t>(tiles_x) * tiles_y;
   const size_t list_stride = budget / 16;              // entries per item: fixed, so that a block finds its list without the header
-  // SBA_GATHER_SUBTILES=0 (A/B measurements): over-budget tiles stay whole and gather from global memory, as in round 2
-  const bool subtiles = [] { const char* e = std::getenv("SBA_GATHER_SUBTILES"); return !(e && e[0] == '0'); }();
+  // SBA_GATHER_SUBTILES=1: an over-budget tile is split into its four 16 x 16 quarters, each of which always fits the
+  // budget, so that EVERY tile is staged.  Built and measured in round 3 (512 frames 3840x1920 -> S = 600, same box, A/B):
+  // 3.49 ms per batch with the quarters against 3.37 ms with the whole tiles gathering from global memory -- 3.6 % SLOWER.
+  // At the pole centres every pixel sits in its own 16-byte chunk and its own cache line: staging moves the same number
+  // of lines through one more hop (LDS) and quadruples the blocks.  Kept as an option, off by default.
+  const bool subtiles = [] { const char* e = std::getenv("SBA_GATHER_SUBTILES"); return e && e[0] == '1'; }();
   std::vector<TileHdr> hdr;
   std::vector<unsigned> chunk_list;
   std::vector<unsigned short> lds_offset;
