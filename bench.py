@@ -11,7 +11,8 @@ components + 2 f64 depths), f64 arithmetic.  At N > 1: one GPU's shard of BASELI
 correspondences sharded 8xMI355X") = 12.5M of the same correspondences per GPU, one RCCL all-reduce of the
 24-double pack per step (the collective north_star names; `--transport peer` selects the direct xGMI exchange).
 At N = 1 the line also carries `c1`: BASELINE config C1 (the reference's real workload: 2 048 matches, initial guess + d-only +
-rot-only + tran-only end to end, GPU beside the oracle's pipeline on the host cores; `--no-c1-leg`), `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
+rot-only + tran-only end to end, GPU beside the oracle's pipeline on the host cores; `--no-c1-leg`, which also drops `c2`:
+BASELINE config C2, 1M rotation-only), `c5`: BASELINE config C5 (256 pairs x 50k: batched step, per-pair LM, 512-frame remap) from a
 child run of `--workload c5` after the timed region (`--no-c5-leg` skips it), and `stages`: the 8-point initial guess and the
 bounded d-only stage of `solve_problem` on the resident problem (`--no-stage-leg`).
 At N > 1, only on request (`--peer-trial` / SBA_BENCH_PEER_TRIAL=1), the line also carries `peer_trial`: after the
@@ -258,7 +259,8 @@ def run_c5(a):
         ms = e0.elapsed_time(e1) / 3
         remap = {"frames": F, "ms_per_batch": ms, "frames_per_s": F / (ms * 1e-3),
                  "algorithmic_GBps": F * S * 6 * S * 6 / (ms * 1e-3) / 1e9,
-                 "what": "sba_equi2cube_device: 3840x1920 8UC3 frames -> 600 x 3600 strips, 3 B gathered + 3 B stored per pixel"}
+                 "what": "sba_equi2cube_device: 3840x1920 8UC3 frames -> 600 x 3600 strips, 3 B gathered + 3 B stored per pixel",
+                 **remap_rooflines(F, S, ms)}
         del src, dst
     if rank == 0:
         total = B * n * world
@@ -318,6 +320,28 @@ def run_c5(a):
         dist.destroy_process_group()
 
 
+def remap_rooflines(frames: int, S: int, ms: float):
+    """The remap is a byte gather, not a stream: priced against HBM by its algorithmic bytes (6 B per output pixel) AND
+    against the L1's tag pipeline, which is what a scattered gather exercises -- tag look-ups per frame from the committed
+    rocprofv3 pass of gather_tiled_kernel (profiles/pmc_gather_latest.json: TCP_TOTAL_CACHE_ACCESSES), one look-up per
+    cycle and CU at the 2.4 GHz peak clock as the ceiling.  Neither is saturated (profiles/r03_gather_subtiles_ab.md)."""
+    t = ms * 1e-3
+    out = {"roofline": {"bound": "hbm", "achieved": frames * S * 6 * S * 6 / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": frames * S * 6 * S * 6 / t / 1e9 / HBM_PEAK_GBPS, "traffic": None}}
+    try:
+        d = json.loads((ROOT / "profiles" / "pmc_gather_latest.json").read_text())
+        if d["geometry"] == {"H": 1920, "W": 3840, "S": S}:
+            look = d["tag_lookups_per_frame"] * frames / t / 1e9
+            peak = 256 * 2.4
+            out["roofline"]["traffic"] = (d["hbm_read_bytes_per_frame"] + d["hbm_write_bytes_per_frame"]) * frames
+            out["roofline_l1"] = {"bound": "l1", "achieved": look, "peak": peak, "unit": "G tag look-ups/s", "frac": look / peak,
+                                  "tag_lookups_per_frame": d["tag_lookups_per_frame"],
+                                  "peak_what": "256 CUs x 2.4 GHz x one tag look-up per cycle", "source": "profiles/pmc_gather_latest.json"}
+    except Exception:
+        pass
+    return out
+
+
 def pmc_traffic_named(kernel_prefix: str, units: int):
     """HBM bytes per launch of a secondary kernel from the committed stage profile (profiles/pmc_stages_latest.json)."""
     try:
@@ -351,6 +375,31 @@ def stage_leg(p, c, n: int):
                               "ms_total": s.seconds_total * 1e3, "us_per_pass": s.seconds_total / max(s.num_evaluations, 1) * 1e6,
                               "algorithmic_bytes_per_pass": n * 96, "termination": s.termination}
         return out
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
+
+def c2_leg(device_index: int, steps: int, warmup: int):
+    """N = 1, after the timed region: BASELINE config C2 -- 1M synthetic correspondences, rotation-only BA (48 B per evaluation):
+    K host-synchronous steps, the sweep kernel between HIP events, and the rot-only LM."""
+    try:
+        from spherical_bundle_adjuster_amd import api, synthetic
+        n = 1_000_000
+        c = synthetic.rotation_only(n, seed=synthetic.BASE_SEED + 1)
+        with api.Problem(device_index) as p:
+            p.upload(c.x1, c.x2)
+            p.eval_launch_times(api.MODE_ROT, c.rot_init, c.tran_init, repeat=200)
+            p.eval_steps(api.MODE_ROT, c.rot_init, c.tran_init, steps=max(warmup, 1))
+            _, seconds = p.eval_steps(api.MODE_ROT, c.rot_init, c.tran_init, steps=steps)
+            _, _, sweep_ms = p.eval_timed(api.MODE_ROT, c.rot_init, c.tran_init, repeat=steps)
+            p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
+            r, t, s = p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
+        return {"ok": True, "workload": "1M synthetic correspondences, rotation-only (BASELINE config C2), 48 B per evaluation",
+                "evals_per_s": n * steps / seconds, "ms_per_step": seconds / steps * 1e3, "kernel_ms": sweep_ms,
+                "roofline": {"bound": "hbm", "achieved": n * 48 / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": n * 48 / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                "lm": {"iterations": s.num_iterations, "iters_per_s": s.num_iterations / s.seconds_total if s.seconds_total > 0 else None,
+                       "termination": s.termination, "rot_err_rad": float(abs(r - c.rot_true).max())}}
     except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
@@ -738,6 +787,7 @@ def main():
             out["stages"] = stage_leg(p, c, a.n)
         if world == 1 and not rehearsal and not a.no_c1_leg:
             out["c1"] = c1_leg(device_index)
+            out["c2"] = c2_leg(device_index, a.steps, a.warmup)
         if world == 1 and not rehearsal and not a.no_c5_leg and rt and a.store == "f64":
             p.close()                       # the child gets the GPU to itself
             out["c5"] = c5_leg(a.steps, a.warmup)

@@ -189,6 +189,9 @@ def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
     assert c5["ok"], c5
     assert c5["roofline"]["kernel"].startswith("batch_step_kernel") and 0.3 < c5["roofline"]["frac"] < 1.0
     assert c5["lm"]["all_converged"] and c5["equi2cube"]["frames"] == 512
+    # the remap is priced against HBM by its algorithmic bytes and against the L1 tag pipeline, its real neighbourhood
+    assert c5["equi2cube"]["roofline"]["bound"] == "hbm" and c5["equi2cube"]["roofline_l1"]["bound"] == "l1"
+    assert 0.05 < c5["equi2cube"]["roofline_l1"]["frac"] < 1.0
     st = b["stages"]
     assert st["ok"] and st["depth_stage"]["termination"].startswith("CONVERGENCE") and st["initial_guess_ms_80_trials"] > 0
     # config C1, the reference's real workload end to end: resident kernels, launch per sweep and the oracle on the host
@@ -199,3 +202,5 @@ def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
     assert c1["max_abs_rot_diff_gpu_vs_cpu"] < 1e-6 and c1["max_abs_rot_diff_resident_vs_launch"] < 1e-10
     assert 0 < c1["gpu_resident"]["total_us"] and 0 < c1["cpu_oracle"]["total_us"]
     assert b["cold"]["value"] > 0
+    c2 = b["c2"]
+    assert c2["ok"] and c2["lm"]["termination"].startswith("CONVERGENCE") and 0.1 < c2["roofline"]["frac"] < 1.0
