@@ -222,7 +222,12 @@ __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ tab
 // which by itself is worth most of the gain (the sources of vertically neighbouring output pixels share cache lines:
 // 9.83 us per frame for the row-major pixel-per-lane kernel, 7.14-7.36 us for 32 x 16 / 32 x 32 tiles without staging,
 // 6.64 us with it).
-constexpr int kTileW = 32, kTileH = 32, kTilePx = kTileW * kTileH, kTileLanePx = kTilePx / 256;
+// A tile is 1024 output pixels, 2^wshift wide (SBA_GATHER_TILE_W = 32, 64 or 128 when a table is built; the tile is then 32, 16
+// or 8 rows high).  The memory system fetches 128-byte lines whatever a request asks for (tools/chunk_probe.hip: random
+// 64-byte runs stream at 3.2 TB/s, random 128-byte runs at 6.2 TB/s), and a tile row's source segment is ~3-4 bytes per
+// output pixel: the wider the tile, the larger the used share of the lines it touches.
+constexpr int kTilePx = 1024, kTileLanePx = kTilePx / 256;
+constexpr int kTileWDefault = 32;
 // bytes per frame and tile.  Measured on 256 frames 3840x1920 -> S = 600, two frames per block (profiles/r02_gather_sweep.log):
 // 6 / 8 / 12 / 16 / 24 KiB = 7.35 / 6.64-6.95 / 6.82-7.10 / 8.18 / 8.19 us per frame (31 / 72 / 89 / 94 / 100 % of the
 // tiles staged): a larger budget stages more tiles but leaves fewer blocks per CU.
@@ -232,7 +237,7 @@ constexpr int kTileLdsBudget = 8192;
 // four 16 x 16 quarters (1 pixel per lane; at most 2 x 256 chunks = 8 KiB, so a quarter always fits the budget).
 // chunks == 0: not staged (list over budget, or reaching past the end of the frame), the pixels then come straight from
 // global memory.  The item's list is chunk_list[item * list_stride ...], its LDS offsets lds_offset[item * kTilePx ...].
-struct TileHdr { unsigned chunks; unsigned short x0, y0; unsigned short shift, pad; };    // shift = log2(edge): 5 or 4
+struct TileHdr { unsigned chunks; unsigned short x0, y0; unsigned char wshift, pxshift; unsigned short pad; };   // width 2^wshift, 2^pxshift pixels
 static_assert(sizeof(TileHdr) == 12, "TileHdr layout");
 
 template <bool PACK>
@@ -262,12 +267,12 @@ __global__ __launch_bounds__(256) void gather_tiled_kernel(const int* __restrict
   for (int m = 0; m < 2; ++m) entry[m] = t + 256u * m < list_stride ? list[t + 256 * m] : 0u;
   const TileHdr h = hdr[tile];
   const int f0 = static_cast<int>(group) * frames_per_block, f1 = min(batch, f0 + frames_per_block);
-  const int edge_mask = (1 << h.shift) - 1, item_px = 1 << (2 * h.shift);       // 1024 or 256 pixels
+  const int edge_mask = (1 << h.wshift) - 1, item_px = 1 << h.pxshift;          // 1024 or 256 pixels
   size_t g[kTileLanePx];
   bool active[kTileLanePx];
 #pragma unroll
   for (int m = 0; m < kTileLanePx; ++m) {
-    const int q = t + 256 * m, orow = h.y0 + (q >> h.shift), ocol = h.x0 + (q & edge_mask);
+    const int q = t + 256 * m, orow = h.y0 + (q >> h.wshift), ocol = h.x0 + (q & edge_mask);
     active[m] = q < item_px && ocol < out_w && orow < out_h;
     g[m] = static_cast<size_t>(orow) * out_w + ocol;
   }
@@ -460,7 +465,12 @@ int build_tiles(Table* t, hipStream_t stream) {
     const long v = std::atol(e);
     if (v >= 16 && v <= 32768) budget = static_cast<size_t>(v);
   }
-  const int tiles_x = (out_w + kTileW - 1) / kTileW, tiles_y = (out_h + kTileH - 1) / kTileH;
+  int tile_w = kTileWDefault;
+  if (const char* e = std::getenv("SBA_GATHER_TILE_W")) { const int v = std::atoi(e); if (v == 32 || v == 64 || v == 128) tile_w = v; }
+  const int tile_h = kTilePx / tile_w;
+  int tile_wshift = 0;
+  while ((1 << tile_wshift) < tile_w) ++tile_wshift;
+  const int tiles_x = (out_w + tile_w - 1) / tile_w, tiles_y = (out_h + tile_h - 1) / tile_h;
   const size_t ntiles = static_cast<size_t>(tiles_x) * tiles_y;
   const size_t list_stride = budget / 16;              // entries per item: fixed, so that a block finds its list without the header
   // SBA_GATHER_SUBTILES=1: an over-budget tile is split into its four 16 x 16 quarters, each of which always fits the
@@ -474,10 +484,11 @@ int build_tiles(Table* t, hipStream_t stream) {
   std::vector<unsigned short> lds_offset;
   std::vector<unsigned> ids;
   unsigned lds_max = 0;
-  // One work item: the square of edge 2^shift at (x0, y0).  Returns false -- and appends nothing -- when its chunk list
-  // is over budget and `must` is not set; with `must` an over-budget (or past-the-end) item is appended un-staged.
-  auto add_item = [&](int x0, int y0, int shift, bool must) -> bool {
-    const int edge = 1 << shift, px = edge * edge;
+  // One work item: the 2^pxshift pixels of the rectangle 2^wshift wide at (x0, y0).  Returns false -- and appends nothing --
+  // when its chunk list is over budget and `must` is not set; with `must` an over-budget (or past-the-end) item is
+  // appended un-staged.
+  auto add_item = [&](int x0, int y0, int shift, int pxshift, bool must) -> bool {
+    const int edge = 1 << shift, px = 1 << pxshift;
     ids.clear();
     for (int q = 0; q < px; ++q) {
       const int orow = y0 + (q >> shift), ocol = x0 + (q & (edge - 1));
@@ -496,7 +507,7 @@ int build_tiles(Table* t, hipStream_t stream) {
     if (!stage && !must && ids.size() * 16 > budget) return false;
     const size_t item = hdr.size();
     hdr.push_back(TileHdr{stage ? static_cast<unsigned>(ids.size()) : 0u, static_cast<unsigned short>(x0), static_cast<unsigned short>(y0),
-                          static_cast<unsigned short>(shift), 0});
+                          static_cast<unsigned char>(shift), static_cast<unsigned char>(pxshift), 0});
     chunk_list.resize((item + 1) * list_stride, 0u);
     lds_offset.resize((item + 1) * kTilePx, 0xffff);
     if (!stage) return true;
@@ -516,11 +527,13 @@ int build_tiles(Table* t, hipStream_t stream) {
   if (out_w > 0xffff || out_h > 0xffff) return SBA_OK;           // item origins are 16-bit: such outputs keep the untiled kernel
   unsigned staged = 0;
   for (size_t tile = 0; tile < ntiles; ++tile) {
-    const int x0 = static_cast<int>(tile % tiles_x) * kTileW, y0 = static_cast<int>(tile / tiles_x) * kTileH;
+    const int x0 = static_cast<int>(tile % tiles_x) * tile_w, y0 = static_cast<int>(tile / tiles_x) * tile_h;
     const size_t first = hdr.size();
-    if (!add_item(x0, y0, 5, !subtiles))
-      for (int sub = 0; sub < 4; ++sub)      // over budget: its four 16 x 16 quarters, each at most 2 x 256 chunks
-        if (x0 + (sub & 1) * 16 < out_w && y0 + (sub >> 1) * 16 < out_h) (void)add_item(x0 + (sub & 1) * 16, y0 + (sub >> 1) * 16, 4, true);
+    if (!add_item(x0, y0, tile_wshift, 10, !subtiles))
+      for (int sub = 0; sub < 4; ++sub) {    // over budget: its four quarters (half as wide, half as high), each at most 2 x 256 chunks
+        const int sx = x0 + (sub & 1) * (tile_w / 2), sy = y0 + (sub >> 1) * (tile_h / 2);
+        if (sx < out_w && sy < out_h) (void)add_item(sx, sy, tile_wshift - 1, 8, true);
+      }
     bool all = true;
     for (size_t k = first; k < hdr.size(); ++k) all = all && hdr[k].chunks > 0;
     if (all) ++staged;

@@ -402,6 +402,21 @@ def test_gather_paths_agree_and_tiles_are_staged(oracle, H, W, S, F):
         assert staged.value >= tiles.value - 4, (staged.value, tiles.value)
     finally:
         del os.environ["SBA_GATHER_SUBTILES"]
+    # wider tiles (64 x 16, 128 x 8 output pixels; SBA_GATHER_TILE_W, read when a table is built): byte-exact all the same
+    for k, tw in enumerate(("64", "128")):
+        os.environ["SBA_GATHER_TILE_W"] = tw
+        try:
+            S3 = S - 2 - k
+            want3 = np.stack([oracle.equi2cube(frames[f], S3, clamp=True)[0] for f in range(F)])
+            dst3 = torch.zeros((F, S3, 6 * S3, 3), dtype=torch.uint8, device="cuda")
+            cabi.check(lib, lib.sba_equi2cube_device(0, C.c_void_p(stream), C.c_void_p(src.data_ptr()), H, W, S3, F,
+                                                     C.c_void_p(dst3.data_ptr())))
+            torch.cuda.synchronize()
+            assert np.array_equal(dst3.cpu().numpy(), want3), tw
+            assert lib.sba_map_table_tiles(0, 0, S3, H, W, C.byref(tiles), C.byref(staged), C.byref(lds)) == 0
+            assert tiles.value == -(-S3 // (1024 // int(tw))) * -(-6 * S3 // int(tw)) and staged.value > 0
+        finally:
+            del os.environ["SBA_GATHER_TILE_W"]
     # a source that does not start on a 16-byte boundary
     raw = torch.zeros(frames.size + 64, dtype=torch.uint8, device="cuda")
     shifted = raw[4:4 + frames.size]

@@ -23,6 +23,19 @@ with api.Batch(0) as b:
     start = acc[..., 4]
     print("block start spread within a step [us]: mean %.2f max %.2f" % (((start.max(axis=1) - start.min(axis=1)) / 100).mean(),
                                                                          ((start.max(axis=1) - start.min(axis=1)) / 100).max()))
+    # where the kernel's time between HIP events goes beyond a block's own 121 us: per step, every block's end stamp
+    # (start + its four phases) against the first block's start -- the in-kernel span -- and against the mean block
+    end = start + acc[..., :4].sum(axis=2)
+    span = (end.max(axis=1) - start.min(axis=1)) / 100
+    print("in-kernel span (first block start -> last block end, thread 0's clock) [us]: mean %.2f min %.2f max %.2f" % (span.mean(), span.min(), span.max()))
+    print("last block end - mean block end [us]: mean %.2f; slowest block's sweep+fold - mean sweep+fold [us]: mean %.2f"
+          % (((end.max(axis=1) - end.mean(axis=1)) / 100).mean(), (us[..., 2].max(axis=1) - us[..., 2].mean(axis=1)).mean()))
+    late = (end - end.mean(axis=1, keepdims=True)).mean(axis=0) / 100          # per block, mean over steps
+    by_xcd = [late[x::8].mean() for x in range(8)]
+    print("mean lateness of a block's end by blockIdx % 8 [us]:", " ".join("%.2f" % v for v in by_xcd))
+    print("the 8 latest blocks (index: us after the mean end):", ", ".join("%d: %.1f" % (i, late[i]) for i in np.argsort(late)[-8:]))
+    launch_ms = b.step_launch_times(api.MODE_RT, rot0, tran0, repeat=50, depth_mode=api.DEPTH_PER_MATCH)
+    print("kernel between HIP events (profile build) [us]: mean %.2f min %.2f" % (launch_ms.mean() * 1e3, launch_ms.min() * 1e3))
     opt = api.default_lm_options(tran_param=api.TRAN_SPHERE)
     ts = []
     for _ in range(12):
