@@ -29,6 +29,8 @@ struct sba_problem {
   int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
   double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
   size_t epi_scratch_elems = 0;
+  void* depth_scratch = nullptr;   // d-only stage: candidate + scaling planes, block partials, results; kept across calls
+  size_t depth_scratch_bytes = 0;
   void* subset_scratch = nullptr;  // reference sampling: [trials][45] moments, then the [trials][m] index lists; kept across calls
   size_t subset_scratch_bytes = 0;
   double frame_B[9], frame_J[9];  // factored kernel: host-side frame of the last enqueued sweep
@@ -42,6 +44,8 @@ struct sba_problem {
   void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* dplane[2] = {nullptr, nullptr};
   void* plane_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // hipMalloc'ed blocks
+  size_t plane_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // their sizes: an upload that fits reuses them (a hipFree + hipMalloc pair per
+                                                      // plane costs more than the whole upload of a 2 000-match problem)
   size_t plane_stagger = 4352; // SBA_PLANE_STAGGER: plane k starts k * 4352 B (17 x 256 B) into its allocation, so equal
                                // element indices of the 8 streams differ in their low address bits (measured 0-4 %
                                // faster with f64 planes, 3-5 % with f32 planes; never slower)

@@ -160,9 +160,10 @@ using sba::shim::rccl;
 namespace {
 
 int free_planes(sba_problem* p) {
-  for (auto& b : p->plane_base) {
-    if (b) SBA_HIP_TRY(hipFree(b));
-    b = nullptr;
+  for (int k = 0; k < 8; ++k) {
+    if (p->plane_base[k]) SBA_HIP_TRY(hipFree(p->plane_base[k]));
+    p->plane_base[k] = nullptr;
+    p->plane_bytes[k] = 0;
   }
   for (auto& c : p->coord) c = nullptr;
   for (auto& d : p->dplane) d = nullptr;
@@ -173,9 +174,22 @@ int free_planes(sba_problem* p) {
   return SBA_OK;
 }
 
+// Plane k: at least `bytes` bytes, zeroed.  An existing allocation that is large enough -- and not more than four times too
+// large -- is kept (the usual case: one handle fed image pair after image pair of similar size).
+int ensure_plane(sba_problem* p, int k, size_t bytes) {
+  if (!p->plane_base[k] || p->plane_bytes[k] < bytes || p->plane_bytes[k] > 4 * bytes + (size_t(1) << 20)) {
+    if (p->plane_base[k]) SBA_HIP_TRY(hipFree(p->plane_base[k]));
+    p->plane_base[k] = nullptr;
+    p->plane_bytes[k] = 0;
+    SBA_HIP_TRY(hipMalloc(&p->plane_base[k], bytes));
+    p->plane_bytes[k] = bytes;
+  }
+  SBA_HIP_TRY(hipMemsetAsync(p->plane_base[k], 0, bytes, p->stream));
+  return SBA_OK;
+}
+
 int alloc_planes(sba_problem* p, size_t n, bool with_d12, int store) {
-  int rc = free_planes(p);
-  if (rc) return rc;
+  p->uploaded = false;
   const size_t esz = store == SBA_STORE_F64 ? 8 : 4;
   // whole 16-byte vectors, plus one spare vector so that the ragged tail load stays in bounds
   const size_t ppt = static_cast<size_t>(sba::points_per_lane(store));
@@ -184,16 +198,20 @@ int alloc_planes(sba_problem* p, size_t n, bool with_d12, int store) {
   // indices of different planes do not share the low address bits.
   const size_t pad = 8 * p->plane_stagger;
   for (int k = 0; k < 6; ++k) {
-    SBA_HIP_TRY(hipMalloc(&p->plane_base[k], elems * esz + pad));
-    SBA_HIP_TRY(hipMemsetAsync(p->plane_base[k], 0, elems * esz + pad, p->stream));
+    const int rc = ensure_plane(p, k, elems * esz + pad);
+    if (rc) return rc;
     p->coord[k] = static_cast<char*>(p->plane_base[k]) + k * p->plane_stagger;
   }
-  if (with_d12)
-    for (int k = 0; k < 2; ++k) {
-      SBA_HIP_TRY(hipMalloc(&p->plane_base[6 + k], elems * 8 + pad));
-      SBA_HIP_TRY(hipMemsetAsync(p->plane_base[6 + k], 0, elems * 8 + pad, p->stream));
+  for (int k = 0; k < 2; ++k) {
+    if (with_d12) {
+      const int rc = ensure_plane(p, 6 + k, elems * 8 + pad);
+      if (rc) return rc;
       p->dplane[k] = reinterpret_cast<double*>(static_cast<char*>(p->plane_base[6 + k]) + (6 + k) * p->plane_stagger);
+    } else {
+      if (p->plane_base[6 + k]) SBA_HIP_TRY(hipFree(p->plane_base[6 + k]));
+      p->plane_base[6 + k] = nullptr; p->plane_bytes[6 + k] = 0; p->dplane[k] = nullptr;
     }
+  }
   p->n = n;
   p->store = store;
   p->has_d12 = with_d12;
@@ -471,6 +489,7 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->peer_sticky) (void)hipFree(p->peer_sticky);
   if (p->epi_scratch) (void)hipFree(p->epi_scratch);
   if (p->subset_scratch) (void)hipFree(p->subset_scratch);
+  if (p->depth_scratch) (void)hipFree(p->depth_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->res_rec) (void)hipHostFree(p->res_rec);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -576,8 +595,8 @@ int sba_problem_set_depths(sba_problem* p, const double* d12) {
   if (!p->has_d12) {
     const size_t pad = 8 * p->plane_stagger, bytes = std::max<size_t>(p->plane_elems, 1) * 8 + pad;
     for (int k = 0; k < 2; ++k) {
-      SBA_HIP_TRY(hipMalloc(&p->plane_base[6 + k], bytes));
-      SBA_HIP_TRY(hipMemsetAsync(p->plane_base[6 + k], 0, bytes, p->stream));
+      const int rc = ensure_plane(p, 6 + k, bytes);
+      if (rc) return rc;
       p->dplane[k] = reinterpret_cast<double*>(static_cast<char*>(p->plane_base[6 + k]) + (6 + k) * p->plane_stagger);
     }
     p->has_d12 = true;

@@ -44,10 +44,18 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   // work planes: candidate depths, Jacobi scaling, LM diagonal (6 x n doubles), block partials, results.  Zeroed once:
   // the kernel writes whole pairs only, and a candidate plane becomes the problem's depth plane when a step is accepted
   // -- its padding must be zeros like the uploaded planes' (a later per-match sweep loads it in its ragged tail).
-  sba::DeviceBuffer work_buf(&p->poisoned), partials_buf(&p->poisoned), out_buf(&p->poisoned);   // leaked, not freed, if a pass poisons the handle
-  SBA_TRY_HIP(work_buf.alloc(4 * elems * sizeof(double)));
-  SBA_TRY_HIP(hipMemsetAsync(work_buf.ptr, 0, 4 * elems * sizeof(double), p->stream));
-  double* work = work_buf.as<double>();
+  // The scratch lives in the handle and is reused while it fits (three hipMalloc / hipFree pairs per call were a tenth of the
+  // stage at the reference's problem sizes); a handle that gets poisoned simply keeps it.
+  const size_t max_grid_rows = static_cast<size_t>(p->num_cus) * 16 + 1;
+  const size_t need = (4 * elems + (max_grid_rows + 1) * sba::DEPTH_ROW) * sizeof(double);
+  if (p->depth_scratch_bytes < need || p->depth_scratch_bytes > 4 * need + (size_t(1) << 20)) {
+    if (p->depth_scratch) SBA_TRY_HIP(hipFree(p->depth_scratch));
+    p->depth_scratch = nullptr; p->depth_scratch_bytes = 0;
+    SBA_TRY_HIP(hipMalloc(&p->depth_scratch, need));
+    p->depth_scratch_bytes = need;
+  }
+  double* work = static_cast<double*>(p->depth_scratch);
+  SBA_TRY_HIP(hipMemsetAsync(work, 0, 4 * elems * sizeof(double), p->stream));
   double *c1 = work, *c2 = work + elems, *sc1 = work + 2 * elems, *sc2 = work + 3 * elems;
   // one resident wave of blocks (occupancy of the kernel, SBA_DEPTH_BLOCKS_PER_CU caps it), grid-stride inside
   int& occ = p->depth_occ[p->store];
@@ -59,9 +67,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   if (const char* env = std::getenv("SBA_DEPTH_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) cap = v; }
   const int grid = static_cast<int>(std::min<size_t>(((n + 1) / 2 + 255) / 256,
                                                      static_cast<size_t>(p->num_cus) * std::max(1, std::min(occ, cap))));
-  SBA_TRY_HIP(partials_buf.alloc(static_cast<size_t>(std::max(grid, 1)) * sba::DEPTH_ROW * sizeof(double)));
-  SBA_TRY_HIP(out_buf.alloc(sba::DEPTH_ROW * sizeof(double)));
-  double *partials = partials_buf.as<double>(), *out_dev = out_buf.as<double>();
+  double *out_dev = work + 4 * elems, *partials = out_dev + sba::DEPTH_ROW;     // [DEPTH_ROW] results, then [grid][DEPTH_ROW] rows
 
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
