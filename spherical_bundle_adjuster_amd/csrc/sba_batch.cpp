@@ -32,6 +32,7 @@ struct sba_batch {
   bool uploaded = false;
   std::vector<size_t> n;            // matches per pair
   std::vector<size_t> first_vec;    // first 16-byte vector of the pair inside the planes
+  size_t tile_stride = 256;         // vectors between consecutive 256-vector tiles of a pair (256 = contiguous pairs; sba_device.hpp: PairDesc)
   size_t total_vecs = 0;
   void* coord[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double* dplane[2] = {nullptr, nullptr};
@@ -287,10 +288,28 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   for (int g = 0; g < num_pairs; ++g) {
     b->n[g] = offsets[g + 1] - offsets[g];
     b->first_vec[g] = vec;
-    desc[g].first_vec = vec;
-    desc[g].n = b->n[g];
+    desc[g] = sba::PairDesc{vec, b->n[g], sba::kPairTile, 0ull};
     vec += (b->n[g] + ppt - 1) / ppt + 1;
     max_n = std::max(max_n, b->n[g]);
+  }
+  // Layout.  Contiguous pairs (above) make every block of a one-block-per-pair sweep its own sequential stream per plane:
+  // num_pairs x 8 streams.  INTERLEAVED (tile t of every pair side by side, 4 KiB tiles) the blocks, which advance in step,
+  // read one contiguous window of every plane like the single-problem grid-stride sweep does (8 streams): 3-4 % more of the
+  // HBM bandwidth (tools/stream_probe.hip: stride vs chunk; measured on the C5 step: DESIGN.md section 3.5).  It pads
+  // every pair to the longest one's tile count, so it is used when that wastes at most a quarter (SBA_BATCH_INTERLEAVE = 0 /
+  // 1 forces either).
+  const size_t tiles = ((max_n + ppt - 1) / ppt + 1 + sba::kPairTile - 1) / sba::kPairTile;      // of the longest pair, spare vector included
+  const size_t inter_vecs = tiles * static_cast<size_t>(num_pairs) * sba::kPairTile;
+  bool interleave = num_pairs >= 2 && inter_vecs <= vec + vec / 4;
+  if (const char* env = std::getenv("SBA_BATCH_INTERLEAVE")) interleave = num_pairs >= 1 && env[0] != '0';
+  b->tile_stride = sba::kPairTile;
+  if (interleave && max_n > 0) {
+    b->tile_stride = sba::kPairTile * static_cast<size_t>(num_pairs);
+    for (int g = 0; g < num_pairs; ++g) {
+      b->first_vec[g] = static_cast<size_t>(g) * sba::kPairTile;
+      desc[g] = sba::PairDesc{b->first_vec[g], b->n[g], b->tile_stride, 0ull};
+    }
+    vec = inter_vecs;
   }
   b->total_vecs = vec + 1;
   const size_t elems = b->total_vecs * ppt, esz = store == SBA_STORE_F64 ? 8 : 4;
@@ -352,14 +371,14 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
       for (int g = 0; g < num_pairs; ++g)
         SBA_TRY_HIP(sba::launch_aos_to_planes(stage + 3 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
                                               b->coord[3 * side], b->coord[3 * side + 1], b->coord[3 * side + 2],
-                                              store, b->stream));
+                                              store, b->stream, sba::kPairTile * ppt, b->tile_stride * ppt));
       { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
     }
     if (d12) {
       SBA_TRY_HIP(hipMemcpyAsync(stage, d12 + 2 * base, total * 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
       for (int g = 0; g < num_pairs; ++g)
         SBA_TRY_HIP(sba::launch_d12_to_planes(stage + 2 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
-                                              b->dplane[0], b->dplane[1], b->stream));
+                                              b->dplane[0], b->dplane[1], b->stream, sba::kPairTile * ppt, b->tile_stride * ppt));
       { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
     }
   }

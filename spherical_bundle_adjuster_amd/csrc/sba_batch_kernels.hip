@@ -26,25 +26,31 @@ __global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const Sw
   const int tid = threadIdx.x;
   const unsigned pair = blockIdx.x / static_cast<unsigned>(bpp), j = blockIdx.x % static_cast<unsigned>(bpp);
   const SweepParams* __restrict__ P = params + pair;
-  const size_t n = P->n, first = desc[pair].first_vec;
+  const PairDesc dsc = desc[pair];
+  const size_t n = P->n;
   const size_t stride = static_cast<size_t>(bpp) * kBlock;
+  static_assert(kBlock == kPairTile, "a block sweeps one 256-vector tile per trip");
 
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
   const size_t nfull = n / PPT;
+  // logical vector p = (j + k bpp) * 256 + tid lives at plane vector q = first + (j + k bpp) * tile_stride + tid
   size_t p = static_cast<size_t>(j) * kBlock + tid;
+  size_t q = dsc.first_vec + static_cast<size_t>(j) * dsc.tile_stride + tid;
+  const size_t qstride = static_cast<size_t>(bpp) * dsc.tile_stride;
   VecRegs<ST, DEPTH> cur, nxt;
-  if (p < nfull) cur.load(pl, first + p);
+  if (p < nfull) cur.load(pl, q);
   while (p < nfull) {
     const size_t pn = p + stride;
-    if (pn < nfull) nxt.load(pl, first + pn);
+    q += qstride;
+    if (pn < nfull) nxt.load(pl, q);
     consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, P, p, n, acc);
     cur = nxt;
     p = pn;
   }
   if (nfull * PPT != n && j == static_cast<unsigned>(bpp) - 1 && tid == kBlock - 1) {
-    cur.load(pl, first + nfull);
+    cur.load(pl, pair_vector(dsc, nfull));
     consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, P, nfull, n, acc);
   }
   const int lane = tid & 63, wave = tid >> 6;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(1024) void batch_convert_finalize_kernel(const doub
 // (fold order identical to batch_sweep_kernel + batch_convert_finalize_kernel with bpp = 1).  Result in raw_s[24]
 // (LDS), valid after the function returns on every thread (it ends with a barrier).
 template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
-__device__ __forceinline__ void block_sweep_fold(const Planes& pl, size_t first, size_t n, const SweepParams& prm,
+__device__ __forceinline__ void block_sweep_fold(const Planes& pl, const PairDesc& dsc, size_t n, const SweepParams& prm,
                                                  double* __restrict__ wave_out, double* __restrict__ raw_s) {
   constexpr int NACC = AccMap<MODE, KIND>::N;
   constexpr int PPT = Lanes<ST>::PPT;
@@ -192,18 +198,19 @@ __device__ __forceinline__ void block_sweep_fold(const Planes& pl, size_t first,
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-  size_t p = tid;
+  size_t p = tid, q = dsc.first_vec + tid;          // logical vector p = 256 k + tid sits at plane vector first + k tile_stride + tid
   VecRegs<ST, DEPTH> cur, nxt;
-  if (p < nfull) cur.load(pl, first + p);
+  if (p < nfull) cur.load(pl, q);
   while (p < nfull) {
     const size_t pn = p + kBlock;
-    if (pn < nfull) nxt.load(pl, first + pn);
+    q += dsc.tile_stride;
+    if (pn < nfull) nxt.load(pl, q);
     consume<MODE, DEPTH, ST, KIND, LOSS, false>(cur, &prm, p, n, acc);
     cur = nxt;
     p = pn;
   }
   if (nfull * PPT != n && tid == kBlock - 1) {
-    cur.load(pl, first + nfull);
+    cur.load(pl, pair_vector(dsc, nfull));
     consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, &prm, nfull, n, acc);
   }
   const int lane = tid & 63, wave = tid >> 6;
@@ -244,7 +251,8 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(Planes pl, const Pai
   long long tk[6] = {0, 0, 0, 0, 0, 0};
   tk[0] = wall_clock64();
 #endif
-  const size_t n_pair = desc[pair].n, first = desc[pair].first_vec;
+  const PairDesc dsc = desc[pair];
+  const size_t n_pair = dsc.n;
   if (tid == 0) {
     const BatchState st = state[pair];
 #ifdef SBA_STEP_PROFILE
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(Planes pl, const Pai
   const SweepParams prm = prm_s;
   // never read past the pair's own vectors, whatever the host wrote into the state record
   const size_t n = prm.n < n_pair ? prm.n : n_pair;
-  block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, first, n, prm, wave_out, raw_s);
+  block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, dsc, n, prm, wave_out, raw_s);
 #ifdef SBA_STEP_PROFILE
   tk[3] = wall_clock64();
 #endif
@@ -325,7 +333,8 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
   LmSolver* solver = reinterpret_cast<LmSolver*>(solver_mem);
   const int tid = threadIdx.x;
   const unsigned pair = blockIdx.x;
-  const size_t n = desc[pair].n, first = desc[pair].first_vec;
+  const PairDesc dsc = desc[pair];
+  const size_t n = dsc.n;
   __shared__ double depth_s[2];
   if (tid == 0) {
     // io lives in mapped HOST memory: one read of the pair's record here, one write of its result at the end
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     __syncthreads();                        // B1: done_s / the next sweep state are visible to the block
     if (done_s) break;
     const SweepParams prm = prm_s;        // LDS broadcast -> registers, held across the sweep
-    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, first, n, prm, wave_out, raw_s);   // two barriers, the last one at its end
+    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, dsc, n, prm, wave_out, raw_s);   // two barriers, the last one at its end
   }
   if (tid == 0) {
     BatchLmIo res;
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void resident_sweep_kernel(Planes pl, unsig
     __builtin_memcpy(&n_cmd, &nd, sizeof(n_cmd));
     const size_t n = n_cmd < n_resident ? n_cmd : n_resident;      // never past the resident matches, whatever the record says
     prm.n = n;
-    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, 0, n, prm, wave_out, raw_s);
+    block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, PairDesc{0ull, n, kPairTile, 0ull}, n, prm, wave_out, raw_s);
   }
   __syncthreads();
   if (tid < 64) {

@@ -108,10 +108,22 @@ hipError_t launch_publish(const double* pack_dev, double* pack_host_dev, unsigne
 // Batched problems (config C5): pair g owns vectors [first_vec, first_vec + ceil(n/PPT)) of the shared planes and
 // params[g] (its own R|t; params[g].n = 0 skips the pair).  bpp blocks per pair; partials [num_pairs*bpp][kRow];
 // packs [num_pairs][24] in the selected kernel's layout.
+// Vector p of a pair (p = 0, 1, ...: 16 bytes of every coordinate plane) sits at plane vector
+//     first_vec + (p / 256) * tile_stride + (p % 256):
+// tile_stride = 256: the pair's vectors are contiguous; tile_stride = 256 * num_pairs, first_vec = 256 * pair: the pairs are
+// INTERLEAVED in 4 KiB tiles (tile t of every pair side by side), so that blocks that sweep their own pairs in step with one
+// another read one contiguous window of every plane -- the access pattern of the single-problem grid-stride sweep -- instead of
+// num_pairs x 8 separate sequential streams.
 struct PairDesc {
   unsigned long long first_vec;
   unsigned long long n;
+  unsigned long long tile_stride;
+  unsigned long long pad_;
 };
+constexpr unsigned long long kPairTile = 256;   // vectors per tile = threads per sweep block
+SBA_HD inline unsigned long long pair_vector(const PairDesc& d, unsigned long long p) {
+  return d.first_vec + (p / kPairTile) * d.tile_stride + (p % kPairTile);
+}
 // What the host hands over per pair and step (mapped pinned host memory, 80 B per pair): the point to evaluate at and
 // the number of matches that take part (0 = pair already converged).
 struct BatchState {
@@ -158,12 +170,13 @@ hipError_t launch_batch_step(int mode, int depth, int store, int kind, double hu
                              int num_pairs, int bpp, double* partials, double* packs, double* packs_host,
                              unsigned long long seq, hipStream_t stream);
 
-// AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.
+// AoS (cv::Point3d layout, double[3n]) -> planes, element offset `first`, count `n`.  tile_stride_elems != 0 (batched,
+// interleaved layout): element i goes to first + (i / tile_elems) * tile_stride_elems + i % tile_elems.
 hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void* px, void* py,
-                                void* pz, int store, hipStream_t stream);
+                                void* pz, int store, hipStream_t stream, size_t tile_elems = 0, size_t tile_stride_elems = 0);
 // d12 (double[2n]) -> two f64 planes.
 hipError_t launch_d12_to_planes(const double* d12, size_t n, size_t first, double* d1, double* d2,
-                                hipStream_t stream);
+                                hipStream_t stream, size_t tile_elems = 0, size_t tile_stride_elems = 0);
 hipError_t launch_planes_to_d12(const double* d1, const double* d2, size_t n, double* d12,
                                 hipStream_t stream);
 

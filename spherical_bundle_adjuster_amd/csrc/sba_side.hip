@@ -6,22 +6,30 @@ namespace sba {
 namespace {
 
 // ---- layout conversion at upload time (once per problem, not per LM iteration) ---------------
+// tile_elems == 0: element i -> first + i.  Otherwise (interleaved batch layout, sba_device.hpp: PairDesc): tiles of
+// tile_elems consecutive elements sit tile_stride_elems apart.
+__device__ __forceinline__ size_t tiled_index(size_t first, size_t i, size_t tile_elems, size_t tile_stride_elems) {
+  return tile_elems == 0 ? first + i : first + (i / tile_elems) * tile_stride_elems + i % tile_elems;
+}
 template <typename ST>
 __global__ void aos_to_planes_kernel(const double* __restrict__ aos, size_t n, size_t first,
-                                     ST* __restrict__ px, ST* __restrict__ py, ST* __restrict__ pz) {
+                                     ST* __restrict__ px, ST* __restrict__ py, ST* __restrict__ pz, size_t tile_elems,
+                                     size_t tile_stride_elems) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  px[first + i] = static_cast<ST>(aos[3 * i + 0]);
-  py[first + i] = static_cast<ST>(aos[3 * i + 1]);
-  pz[first + i] = static_cast<ST>(aos[3 * i + 2]);
+  const size_t o = tiled_index(first, i, tile_elems, tile_stride_elems);
+  px[o] = static_cast<ST>(aos[3 * i + 0]);
+  py[o] = static_cast<ST>(aos[3 * i + 1]);
+  pz[o] = static_cast<ST>(aos[3 * i + 2]);
 }
 __global__ void d12_to_planes_kernel(const double* __restrict__ d12, size_t n, size_t first,
-                                     double* __restrict__ d1, double* __restrict__ d2) {
+                                     double* __restrict__ d1, double* __restrict__ d2, size_t tile_elems, size_t tile_stride_elems) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double2 d = reinterpret_cast<const double2*>(d12)[i];
-  d1[first + i] = d.x;
-  d2[first + i] = d.y;
+  const size_t o = tiled_index(first, i, tile_elems, tile_stride_elems);
+  d1[o] = d.x;
+  d2[o] = d.y;
 }
 __global__ void planes_to_d12_kernel(const double* __restrict__ d1, const double* __restrict__ d2,
                                      size_t n, double* __restrict__ d12) {
@@ -70,23 +78,23 @@ __global__ void keypoints_to_planes_kernel(const uint8_t* __restrict__ kp_left, 
 }  // namespace
 
 hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void* px, void* py,
-                                void* pz, int store, hipStream_t stream) {
+                                void* pz, int store, hipStream_t stream, size_t tile_elems, size_t tile_stride_elems) {
   if (n == 0) return hipSuccess;
   const unsigned grid = static_cast<unsigned>((n + 255) / 256);
   if (store == 0)
     hipLaunchKernelGGL((aos_to_planes_kernel<double>), dim3(grid), dim3(256), 0, stream, aos, n, first,
-                       static_cast<double*>(px), static_cast<double*>(py), static_cast<double*>(pz));
+                       static_cast<double*>(px), static_cast<double*>(py), static_cast<double*>(pz), tile_elems, tile_stride_elems);
   else
     hipLaunchKernelGGL((aos_to_planes_kernel<float>), dim3(grid), dim3(256), 0, stream, aos, n, first,
-                       static_cast<float*>(px), static_cast<float*>(py), static_cast<float*>(pz));
+                       static_cast<float*>(px), static_cast<float*>(py), static_cast<float*>(pz), tile_elems, tile_stride_elems);
   return hipGetLastError();
 }
 
 hipError_t launch_d12_to_planes(const double* d12, size_t n, size_t first, double* d1, double* d2,
-                                hipStream_t stream) {
+                                hipStream_t stream, size_t tile_elems, size_t tile_stride_elems) {
   if (n == 0) return hipSuccess;
   const unsigned grid = static_cast<unsigned>((n + 255) / 256);
-  hipLaunchKernelGGL(d12_to_planes_kernel, dim3(grid), dim3(256), 0, stream, d12, n, first, d1, d2);
+  hipLaunchKernelGGL(d12_to_planes_kernel, dim3(grid), dim3(256), 0, stream, d12, n, first, d1, d2, tile_elems, tile_stride_elems);
   return hipGetLastError();
 }
 

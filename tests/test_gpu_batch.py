@@ -44,6 +44,39 @@ def test_batch_eval_matches_oracle(oracle, kind, store):
                     assert np.abs(packs[g] - ref).max() <= REL_TOL_F64 * scale, (mode, dm, g, sizes[g])
 
 
+@pytest.mark.parametrize("sizes", [[1, 0, 63, 64, 65, 1000, 2, 513, 3001, 7, 255, 256, 257, 511, 512, 1025],
+                                   [100_003, 0, 99_999, 100_000]], ids=["ragged_one_block_per_pair", "several_blocks_per_pair"])
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+def test_interleaved_pair_layout_is_bit_identical_to_the_contiguous_one(sizes, store, monkeypatch):
+    """Batches whose pairs are of similar length are laid out INTERLEAVED (tile t of every pair side by side in 4 KiB tiles,
+    so that blocks sweeping their own pairs in step read one contiguous window per plane); ragged batches stay contiguous
+    (SBA_BATCH_INTERLEAVE forces either).  Only addresses change -- every lane consumes the same vectors in the same
+    order -- so packs and solves must agree to the last bit, with one block per pair (one-launch step, device LM) and with
+    several (three-kernel chain, host lock-step LM), ragged tails, empty pairs, f64 and f32 planes."""
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=3100)
+    B = len(sizes)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    d1 = np.linspace(0.8, 1.7, B); d2 = np.linspace(1.3, 0.6, B)
+    got = {}
+    for layout in ("0", "1"):
+        monkeypatch.setenv("SBA_BATCH_INTERLEAVE", layout)
+        with api.Batch(0) as b:
+            b.upload(x1, x2, off, d12, store=store)
+            packs = [b.eval(mode, rot0, tran0, d1, d2, 1.0, dm) for mode in (api.MODE_ROT, api.MODE_TRAN, api.MODE_RT)
+                     for dm in (api.DEPTH_PER_MATCH, api.DEPTH_UNIFORM)]
+            b.set_kernel(api.KERNEL_EXPLICIT)
+            packs.append(b.eval(api.MODE_RT, rot0, tran0, d1, d2, 1.0, api.DEPTH_PER_MATCH))
+            b.set_kernel(api.KERNEL_FACTORED)
+            sol = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH,
+                          options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
+            got[layout] = (packs, sol, b.blocks_per_pair)
+    assert got["0"][2] == got["1"][2]
+    for a, c in zip(got["0"][0], got["1"][0]):
+        assert np.array_equal(a, c)
+    assert np.array_equal(got["0"][1][0], got["1"][1][0]) and np.array_equal(got["0"][1][1], got["1"][1][1])
+    assert [q.num_iterations for q in got["0"][1][2]] == [q.num_iterations for q in got["1"][1][2]]
+
+
 def test_batch_solve_matches_single_problem_solves(oracle):
     sizes = [4000, 0, 2500, 3333, 1, 5000]
     cs, off, x1, x2, d12 = _make_pairs(sizes)
