@@ -393,7 +393,8 @@ def c2_leg(device_index: int, steps: int, warmup: int):
             _, seconds = p.eval_steps(api.MODE_ROT, c.rot_init, c.tran_init, steps=steps)
             _, _, sweep_ms = p.eval_timed(api.MODE_ROT, c.rot_init, c.tran_init, repeat=steps)
             p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
-            r, t, s = p.solve(api.MODE_ROT, c.rot_init, c.tran_init)
+            runs = [p.solve(api.MODE_ROT, c.rot_init, c.tran_init) for _ in range(15)]
+            r, t, s = sorted(runs, key=lambda q: q[2].seconds_total)[len(runs) // 2]          # median solve
         return {"ok": True, "workload": "1M synthetic correspondences, rotation-only (BASELINE config C2), 48 B per evaluation",
                 "evals_per_s": n * steps / seconds, "ms_per_step": seconds / steps * 1e3, "kernel_ms": sweep_ms,
                 "roofline": {"bound": "hbm", "achieved": n * 48 / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -709,7 +710,10 @@ def main():
     # LM iterations per second of a real solve of this workload (secondary metric)
     opt = api.default_lm_options(tran_param=api.TRAN_SPHERE if rt else api.TRAN_FREE)
     p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)         # first call: one-time costs
-    r_s, t_s, summ = p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt)
+    # median of several solves: a single 3-iteration solve is ~0.4 ms and one scheduling hiccup doubles it
+    # (profiles/r03_lm_rate.log); every rank runs the same number of solves (each is a sequence of collectives at N > 1)
+    lm_runs = [p.solve(mode, c.rot_init, c.tran_init, depth_mode=depth_mode, options=opt) for _ in range(7)]
+    r_s, t_s, summ = sorted(lm_runs, key=lambda q: q[2].seconds_total)[len(lm_runs) // 2]
     barrier()
     want_trial = world > 1 and not a.no_peer_trial and (a.peer_trial or os.environ.get("SBA_BENCH_PEER_TRIAL", "0") == "1")
     trial = None
@@ -769,7 +773,7 @@ def main():
             "kernel_only_evals_per_s": a.n / (sweep_ms * 1e-3),
             "device_step_ms": step_ms,
             "lm": {"iters_per_s": summ.num_iterations / summ.seconds_total if summ.seconds_total > 0 else None,
-                   "iterations": summ.num_iterations, "termination": summ.termination,
+                   "what": "median of 7 solves", "iterations": summ.num_iterations, "termination": summ.termination,
                    "rot_err_rad": float(np.abs(r_s - c.rot_true).max()),
                    "tran_err": float(np.abs(t_s - c.tran_true).max())},
             "peer_trial": trial,
