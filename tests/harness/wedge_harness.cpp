@@ -101,8 +101,8 @@ hipError_t launch_batch_step(int, int, int, int, double, const Planes&, const Ba
                              double*, double*, double* host, unsigned long long seq, hipStream_t) {
   publish(host, static_cast<size_t>(24) * np, seq); return hipSuccess;
 }
-hipError_t launch_aos_to_planes(const double*, size_t, size_t, void*, void*, void*, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_d12_to_planes(const double*, size_t, size_t, double*, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_aos_to_planes(const double*, size_t, size_t, void*, void*, void*, int, hipStream_t, size_t, size_t) { return hipSuccess; }
+hipError_t launch_d12_to_planes(const double*, size_t, size_t, double*, double*, hipStream_t, size_t, size_t) { return hipSuccess; }
 hipError_t launch_planes_to_d12(const double*, const double*, size_t, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_depth_step(int, const Planes&, const double*, const double*, double*, double*, double*, double*, const DepthParams&, double*,
                              int, double*, double* host, unsigned long long seq, int, hipStream_t) {
