@@ -13,6 +13,8 @@
 // first trial; a contraction re-runs the pass with alpha < 1 and the stored diagonal (same delta, bit for bit).
 // Two matches per lane, 16-byte accesses (1 KiB per wave instruction) -- HBM-bound: 8-12 loads + 4-8 stores of
 // 8 B per match and iteration (96-128 B).
+#include <cstdlib>
+
 #include "sba_device.hpp"
 #include "sba_resident.hpp"
 
@@ -75,19 +77,29 @@ struct DepthRegs {
 // One lane's share of a pass: its pairs of matches pr, pr + stride, ... -- residuals, Jacobian, damped 2x2 solve, projected
 // candidate (stored to c1 / c2), candidate cost and gradient -- accumulated into the nine per-lane partial reductions
 // r[DEPTH_OUT_*].  Shared by the grid-wide kernel (stride = grid size) and the resident single-block kernel (stride = 256).
-template <typename ST>
+// AHEAD = grid-stride steps whose loads are in flight while the current one is computed on.  A step is ~640 f64 VALU
+// instructions per lane (~4 us per wave): with one step ahead a wave's loads have long landed before it asks for the
+// next ones, so for most of its compute phase it has nothing in flight; two steps ahead keep the memory system fed
+// (+40 VGPRs: 227, still two waves per SIMD).
+template <typename ST, int AHEAD>
 __device__ __forceinline__ void depth_stream(const Planes& pl, const double* __restrict__ d1, const double* __restrict__ d2,
                                              double* __restrict__ c1, double* __restrict__ c2, double* __restrict__ sc1,
                                              double* __restrict__ sc2, const DepthParams& P, size_t pr, size_t stride,
                                              double r[DEPTH_OUT_COUNT]) {
+  static_assert(AHEAD == 1 || AHEAD == 2, "one or two steps of loads in flight");
   const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
   const bool load_scale = !P.first_iteration;
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gdelta = 0, cand_gdelta = 0, gmax = 0, dmax = 0;
-  DepthRegs<ST> cur, nxt;
+  DepthRegs<ST> cur, nxt, nx2;
   if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, load_scale, pr);
+  if (AHEAD == 2 && pr + stride < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, pr + stride);
   while (pr < npairs) {
     const size_t pn = pr + stride;
-    if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, pn);
+    if (AHEAD == 2) {
+      if (pn + stride < npairs) nx2.load(pl, d1, d2, sc1, sc2, load_scale, pn + stride);
+    } else {
+      if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, pn);
+    }
     double NA[2], NB[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -151,6 +163,7 @@ __device__ __forceinline__ void depth_stream(const Planes& pl, const double* __r
     else { store_pair_f64(c1, pr, NA[0], NA[1]); store_pair_f64(c2, pr, NB[0], NB[1]); }
     if (P.first_iteration) { store_pair_f64(sc1, pr, cur.S1[0], cur.S1[1]); store_pair_f64(sc2, pr, cur.S2[0], cur.S2[1]); }
     cur = nxt;
+    if (AHEAD == 2) nxt = nx2;
     pr = pn;
   }
   r[0] = cost; r[1] = model; r[2] = cand_cost; r[3] = step2; r[4] = x2n; r[5] = gdelta; r[6] = cand_gdelta; r[7] = gmax; r[8] = dmax;
@@ -179,7 +192,7 @@ __device__ __forceinline__ double depth_block_fold(const double r[DEPTH_OUT_COUN
 // Two resident 256-thread blocks per CU: 187 VGPRs hold both matches' temporaries and the whole register double buffer.
 // Holding the allocation to 3 / 4 blocks per CU (168 / 128 VGPRs, 84 / 244 B of scratch) was measured and is far worse:
 // 231-279 / 499-517 us per pass against 185 us (profiles/r03_depth_tune.log) -- the spills sit in the hot loop.
-template <typename ST>
+template <typename ST, int AHEAD>
 __global__ __launch_bounds__(256, 2) void depth_step_kernel(Planes pl, const double* __restrict__ d1,
                                                            const double* __restrict__ d2,
                                                            double* __restrict__ c1, double* __restrict__ c2,
@@ -187,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void depth_step_kernel(Planes pl, const dou
                                                            DepthParams P, double* __restrict__ partials) {
   __shared__ double red[4][DEPTH_OUT_COUNT];
   double r[DEPTH_OUT_COUNT];
-  depth_stream<ST>(pl, d1, d2, c1, c2, sc1, sc2, P, static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x,
-                   static_cast<size_t>(gridDim.x) * blockDim.x, r);
+  depth_stream<ST, AHEAD>(pl, d1, d2, c1, c2, sc1, sc2, P, static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x,
+                          static_cast<size_t>(gridDim.x) * blockDim.x, r);
   const double s = depth_block_fold(r, red);
   if (threadIdx.x < DEPTH_OUT_COUNT) partials[static_cast<size_t>(blockIdx.x) * DEPTH_ROW + threadIdx.x] = s;
 }
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void resident_depth_kernel(Planes pl, unsig
     __builtin_memcpy(&n_cmd, &nd, sizeof(n_cmd));
     P.n = n_cmd < n_resident ? n_cmd : n_resident;
     double r[DEPTH_OUT_COUNT];
-    depth_stream<ST>(pl, flip ? b1 : a1, flip ? b2 : a2, flip ? a1 : b1, flip ? a2 : b2, sc1, sc2, P, static_cast<size_t>(tid), 256, r);
+    depth_stream<ST, 1>(pl, flip ? b1 : a1, flip ? b2 : a2, flip ? a1 : b1, flip ? a2 : b2, sc1, sc2, P, static_cast<size_t>(tid), 256, r);
     const double s = depth_block_fold(r, red);
     if (tid < DEPTH_OUT_COUNT) res_s[tid] = s;
   }
@@ -306,7 +319,14 @@ __global__ __launch_bounds__(64 * DEPTH_OUT_COUNT) void depth_finalize_kernel(co
 }  // namespace
 
 typedef void (*DepthFn)(Planes, const double*, const double*, double*, double*, double*, double*, DepthParams, double*);
-DepthFn depth_pick(int store) { return store == 0 ? depth_step_kernel<double> : depth_step_kernel<float>; }
+int depth_ahead() {      // SBA_DEPTH_AHEAD = 1 / 2: grid-stride steps of loads in flight (A/B; profiles/r03_depth_ahead.log)
+  static const int ahead = [] { const char* e = std::getenv("SBA_DEPTH_AHEAD"); return e && e[0] == '1' ? 1 : 2; }();
+  return ahead;
+}
+DepthFn depth_pick(int store) {
+  if (depth_ahead() == 2) return store == 0 ? depth_step_kernel<double, 2> : depth_step_kernel<float, 2>;
+  return store == 0 ? depth_step_kernel<double, 1> : depth_step_kernel<float, 1>;
+}
 
 hipError_t depth_blocks_per_cu(int store, int* blocks) {
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, reinterpret_cast<const void*>(depth_pick(store)), 256, 0);
