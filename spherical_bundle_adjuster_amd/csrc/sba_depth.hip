@@ -78,9 +78,10 @@ struct DepthRegs {
 // candidate (stored to c1 / c2), candidate cost and gradient -- accumulated into the nine per-lane partial reductions
 // r[DEPTH_OUT_*].  Shared by the grid-wide kernel (stride = grid size) and the resident single-block kernel (stride = 256).
 // AHEAD = grid-stride steps whose loads are in flight while the current one is computed on.  A step is ~640 f64 VALU
-// instructions per lane (~4 us per wave): with one step ahead a wave's loads have long landed before it asks for the
-// next ones, so for most of its compute phase it has nothing in flight; two steps ahead keep the memory system fed
-// (+40 VGPRs: 227, still two waves per SIMD).
+// instructions per lane (~4 us per wave), so with one step ahead a wave's loads have long landed before it asks for the
+// next ones -- would two steps ahead (+40 VGPRs: 227, still two waves per SIMD) feed the memory system better?  Measured:
+// no -- 177.4 us per pass against 169.1 us (rocprofv3 averages over 54 launches, same box; profiles/r03_depth_ahead.log).
+// One step ahead is the default; SBA_DEPTH_AHEAD=2 keeps the variant reachable.
 template <typename ST, int AHEAD>
 __device__ __forceinline__ void depth_stream(const Planes& pl, const double* __restrict__ d1, const double* __restrict__ d2,
                                              double* __restrict__ c1, double* __restrict__ c2, double* __restrict__ sc1,
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(64 * DEPTH_OUT_COUNT) void depth_finalize_kernel(co
 
 typedef void (*DepthFn)(Planes, const double*, const double*, double*, double*, double*, double*, DepthParams, double*);
 int depth_ahead() {      // SBA_DEPTH_AHEAD = 1 / 2: grid-stride steps of loads in flight (A/B; profiles/r03_depth_ahead.log)
-  static const int ahead = [] { const char* e = std::getenv("SBA_DEPTH_AHEAD"); return e && e[0] == '1' ? 1 : 2; }();
+  static const int ahead = [] { const char* e = std::getenv("SBA_DEPTH_AHEAD"); return e && e[0] == '2' ? 2 : 1; }();
   return ahead;
 }
 DepthFn depth_pick(int store) {
