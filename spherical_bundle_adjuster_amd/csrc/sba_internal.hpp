@@ -38,6 +38,27 @@ int stream_wait(hipStream_t stream, const char* what, int* poisoned);
 void make_sweep_params(size_t n, int depth_mode, const double rot[3], const double tran[3], double d1, double d2,
                        double huber_delta, SweepParams* prm);
 
+// Bounded wait for a HIP event (same limit and poisoning as stream_wait).
+int event_wait(hipEvent_t ev, const char* what, int* poisoned);
+
+// A handful of host threads that copy one byte range in parallel, again and again (the staging copies of a large upload):
+// the workers spin on a generation counter between copies -- a copy is a few milliseconds apart at most -- and the
+// calling thread takes the first share.
+class CopyPool {
+ public:
+  explicit CopyPool(int threads);
+  ~CopyPool();
+  CopyPool(const CopyPool&) = delete;
+  CopyPool& operator=(const CopyPool&) = delete;
+  void copy(void* dst, const void* src, size_t bytes);
+  int threads() const { return nt_; }
+
+ private:
+  struct Impl;
+  Impl* impl_;
+  int nt_;
+};
+
 // Scratch device memory that is released on every exit path.
 // `poison` (may be null): the owning handle's poison word -- hipFree waits for the device, so a buffer whose handle got
 // poisoned meanwhile is leaked instead of freed.

@@ -29,6 +29,7 @@ struct sba_problem {
   int depth_occ[2] = {0, 0};     // same for depth_step_kernel per [store]
   double* epi_scratch = nullptr; // 8-point moments: [grid][45][64] block partials + [64][45] groups, kept across calls
   size_t epi_scratch_elems = 0;
+  void* upload_pinned[2] = {nullptr, nullptr};   // large uploads: two pinned staging buffers (sba_shim.cpp: upload_common)
   void* depth_scratch = nullptr;   // d-only stage: candidate + scaling planes, block partials, results; kept across calls
   size_t depth_scratch_bytes = 0;
   void* subset_scratch = nullptr;  // reference sampling: [trials][45] moments, then the [trials][m] index lists; kept across calls

@@ -117,6 +117,77 @@ int stream_wait(hipStream_t stream, const char* what, int* poisoned) {
     }
   }
 }
+int event_wait(hipEvent_t ev, const char* what, int* poisoned) {
+  const double limit_s = wait_limit_seconds();
+  std::chrono::steady_clock::time_point t0;
+  bool timing = false;
+  for (unsigned long spins = 0;; ++spins) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return SBA_OK;
+    if (q != hipErrorNotReady) {
+      if (poisoned) *poisoned = 1;
+      return set_error(SBA_ERR_HIP, "%s failed on the device: %s", what, hipGetErrorString(q));
+    }
+    if (spins >= 256) {
+      const auto now = std::chrono::steady_clock::now();
+      if (!timing) { t0 = now; timing = true; }
+      else if (std::chrono::duration<double>(now - t0).count() > limit_s) {
+        if (poisoned) *poisoned = 1;
+        return set_error(SBA_ERR_HIP, "%s: not reached within %.0f s (SBA_WAIT_TIMEOUT_S)", what, limit_s);
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(spins < 4096 ? 20 : 500));
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+}
+
+struct CopyPool::Impl {
+  std::vector<std::thread> pool;
+  std::atomic<unsigned long long> gen{0};
+  std::atomic<int> done{0};
+  std::atomic<bool> quit{false};
+  char* dst = nullptr;
+  const char* src = nullptr;
+  size_t bytes = 0;
+  int nt = 1;
+  void share(int t) const {
+    const size_t per = ((bytes + nt - 1) / nt + 63) & ~size_t(63);
+    const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
+    if (hi > lo) std::memcpy(dst + lo, src + lo, hi - lo);
+  }
+  void loop(int t) {
+    unsigned long long seen = 0;
+    for (;;) {
+      unsigned long spins = 0;
+      while (gen.load(std::memory_order_acquire) == seen) {
+        if (++spins > 20000) std::this_thread::yield(); else __builtin_ia32_pause();
+      }
+      ++seen;
+      if (quit.load(std::memory_order_acquire)) return;
+      share(t);
+      done.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+};
+CopyPool::CopyPool(int threads) : impl_(new Impl()), nt_(std::max(1, threads)) {
+  impl_->nt = nt_;
+  for (int t = 1; t < nt_; ++t) impl_->pool.emplace_back([this, t] { impl_->loop(t); });
+}
+CopyPool::~CopyPool() {
+  impl_->quit.store(true, std::memory_order_release);
+  impl_->gen.fetch_add(1, std::memory_order_acq_rel);
+  for (auto& th : impl_->pool) th.join();
+  delete impl_;
+}
+void CopyPool::copy(void* dst, const void* src, size_t bytes) {
+  impl_->dst = static_cast<char*>(dst); impl_->src = static_cast<const char*>(src); impl_->bytes = bytes;
+  impl_->done.store(0, std::memory_order_relaxed);
+  impl_->gen.fetch_add(1, std::memory_order_acq_rel);
+  impl_->share(0);
+  while (impl_->done.load(std::memory_order_acquire) != nt_ - 1) __builtin_ia32_pause();
+}
+
 int set_error(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -492,11 +563,20 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->depth_scratch) (void)hipFree(p->depth_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->res_rec) (void)hipHostFree(p->res_rec);
+  for (void* q : p->upload_pinned) if (q) (void)hipHostFree(q);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return SBA_OK;
+}
+
+constexpr size_t kPipelinedUploadMin = size_t(1) << 21;     // correspondences: below this one hipMemcpyAsync per array is as fast
+constexpr size_t kUploadChunk = 699050;                     // correspondences per pipelined chunk (16 MiB of xyz)
+
+static bool upload_pipeline_off() {      // SBA_UPLOAD_PIPELINE=0: the single-buffer path at every size (A/B measurements)
+  const char* env = std::getenv("SBA_UPLOAD_PIPELINE");
+  return env && env[0] == '0';
 }
 
 static int upload_common(sba_problem* p, const void* left, const void* right, const void* d12,
@@ -518,8 +598,8 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
       if (d12)
         SBA_HIP_TRY(sba::launch_d12_to_planes(static_cast<const double*>(d12), n, 0, p->dplane[0],
                                               p->dplane[1], p->stream));
-    } else {
-      // Bounded staging buffer: chunks of <= 4M correspondences (96 MB) go H2D then are re-laid
+    } else if (n < kPipelinedUploadMin || upload_pipeline_off()) {
+      // Small and mid-size problems: one staging buffer, chunks of <= 4M correspondences (96 MB) go H2D then are re-laid
       // out as planes on the device.
       const size_t chunk = std::min<size_t>(n, size_t(4) << 20);
       sba::DeviceBuffer stage_buf(&p->poisoned);
@@ -544,6 +624,51 @@ static int upload_common(sba_problem* p, const void* left, const void* right, co
           SBA_HIP_TRY(sba::launch_d12_to_planes(stage, m, first, p->dplane[0], p->dplane[1], p->stream));
           SBA_SYNC(p, "stream synchronisation");
         }
+    } else {
+      // Large problems: the caller's arrays are pageable (std::vector<cv::Point3d>::data()), and a fresh pageable array
+      // reaches the device at 16-30 GB/s through hipMemcpy, against 57 GB/s from pinned memory (tools/h2d_probe.cpp,
+      // profiles/r03_h2d_probe.log).  So: a few host threads copy chunk k + 1 into one of two pinned staging buffers while
+      // the DMA engine moves chunk k to the device and the re-layout kernel turns chunk k - 1 into planes -- three stages
+      // in flight, 51-52 GB/s end to end with 4-8 copy threads.  The pinned buffers live in the handle.
+      const size_t chunk = kUploadChunk;                        // correspondences per chunk: 16 MiB of xyz
+      const size_t chunk_bytes = chunk * 3 * sizeof(double);
+      for (int k = 0; k < 2; ++k)
+        if (!p->upload_pinned[k]) SBA_HIP_TRY(hipHostMalloc(&p->upload_pinned[k], chunk_bytes, hipHostMallocDefault));
+      sba::DeviceBuffer stage_buf(&p->poisoned);
+      SBA_HIP_TRY(stage_buf.alloc(2 * chunk_bytes));
+      char* dev_stage[2] = {stage_buf.as<char>(), stage_buf.as<char>() + chunk_bytes};
+      int threads = 6;
+      if (const char* env = std::getenv("SBA_UPLOAD_THREADS")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) threads = v; }
+      threads = std::max(1, std::min<int>(threads, static_cast<int>(std::thread::hardware_concurrency())));
+      sba::CopyPool pool(threads);
+      hipEvent_t h2d_done[2] = {p->ev0, p->ev1};
+      struct Job { const double* src; int width; int which; };
+      const Job jobs[3] = {{static_cast<const double*>(left), 3, 0}, {static_cast<const double*>(right), 3, 1},
+                           {static_cast<const double*>(d12), 2, 2}};
+      size_t k = 0;
+      for (const Job& job : jobs) {
+        if (!job.src) continue;
+        for (size_t first = 0; first < n; first += chunk, ++k) {
+          const size_t m = std::min(chunk, n - first), bytes = m * job.width * sizeof(double);
+          const int b = static_cast<int>(k & 1);
+          if (k >= 2) {                                        // the DMA out of pinned buffer b has finished
+            const int rc2 = sba::event_wait(h2d_done[b], "upload staging", &p->poisoned);
+            if (rc2) return rc2;
+          }
+          pool.copy(p->upload_pinned[b], job.src + job.width * first, bytes);
+          SBA_HIP_TRY(hipMemcpyAsync(dev_stage[b], p->upload_pinned[b], bytes, hipMemcpyHostToDevice, p->stream));
+          SBA_HIP_TRY(hipEventRecord(h2d_done[b], p->stream));
+          // stream order: this kernel reads dev_stage[b] after the copy above, and the copy of chunk k + 2 into the same
+          // device buffer waits for it
+          double* stage = reinterpret_cast<double*>(dev_stage[b]);
+          if (job.which < 2)
+            SBA_HIP_TRY(sba::launch_aos_to_planes(stage, m, first, p->coord[3 * job.which + 0], p->coord[3 * job.which + 1],
+                                                  p->coord[3 * job.which + 2], store, p->stream));
+          else
+            SBA_HIP_TRY(sba::launch_d12_to_planes(stage, m, first, p->dplane[0], p->dplane[1], p->stream));
+        }
+      }
+      SBA_SYNC(p, "upload");      // before the staging buffer goes out of scope
     }
   }
   SBA_SYNC(p, "stream synchronisation");

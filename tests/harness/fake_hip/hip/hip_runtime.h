@@ -15,7 +15,7 @@ struct hipDeviceProp_t { char name[256]; int multiProcessorCount; };
 struct hipIpcMemHandle_t { char reserved[64]; };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
-enum : unsigned { hipStreamNonBlocking = 1, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000u,
+enum : unsigned { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000u,
                   hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3, hipIpcMemLazyEnablePeerAccess = 1 };
 
 const char* hipGetErrorString(hipError_t);
@@ -43,6 +43,7 @@ hipError_t hipEventCreate(hipEvent_t*);
 hipError_t hipEventDestroy(hipEvent_t);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);
+hipError_t hipEventQuery(hipEvent_t);
 hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*);
 hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned);

@@ -60,6 +60,7 @@ hipError_t hipStreamQuery(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(std::malloc(8)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return g_wedged ? hipErrorNotReady : hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { blocking_call("hipEventSynchronize"); return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return hipSuccess; }
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorUnknown; }
