@@ -105,6 +105,35 @@ def test_empty_and_reupload(problem, oracle):
     assert_normal_eq_close(got, oracle.evaluate(0, c2.x1, c2.x2, c2.rot_init, c2.tran_init), REL_TOL_F64)
 
 
+def test_reuploads_reuse_or_replace_the_resident_planes(oracle):
+    """A handle keeps its plane allocations from upload to upload while they fit (one handle fed image pair after image
+    pair): every sequence of sizes, storage types and with / without per-match depths must give the oracle's numbers --
+    no stale tail from a larger predecessor (f32 vectors hold 4 matches, f64 vectors 2: the padding differs), depths gone
+    when an upload brings none, the d-only stage's scratch following along."""
+    steps = [(5000, api.STORE_F64, True), (4097, api.STORE_F32, True), (4999, api.STORE_F64, False), (63, api.STORE_F32, False),
+             (40000, api.STORE_F64, True), (6, api.STORE_F64, True), (39999, api.STORE_F32, True)]
+    with api.Problem(0) as p:
+        for k, (n, store, with_d) in enumerate(steps):
+            c = synthetic.full_rt(n, seed=7700 + k)
+            x1, x2 = (c.x1, c.x2) if store == api.STORE_F64 else (c.x1.astype(np.float32).astype(np.float64),
+                                                                  c.x2.astype(np.float32).astype(np.float64))
+            p.upload(c.x1, c.x2, c.d12 if with_d else None, store=store)
+            tol = REL_TOL_F64
+            got = p.eval(api.MODE_ROT, c.rot_init, c.tran_init, 1.3, 0.7)
+            assert_normal_eq_close(got, oracle.evaluate(0, x1, x2, c.rot_init, c.tran_init, 1.3, 0.7), tol, f"step {k} uniform")
+            if with_d:
+                got = p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+                assert_normal_eq_close(got, oracle.evaluate(2, x1, x2, c.rot_init, c.tran_init, d12=c.d12), tol, f"step {k} per match")
+                if n >= 1000 and store == api.STORE_F64:
+                    d, sd = p.solve_depths(c.rot_init, c.tran_init)
+                    dref, sref, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, c.d12)
+                    assert rc == 0 and sd.num_iterations == sref.num_iterations
+                    assert np.abs(d - dref).max() <= 1e-9 * max(1.0, np.abs(dref).max())
+            else:
+                with pytest.raises(api.SbaError):
+                    p.eval(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+
+
 def test_error_behaviour(problem):
     c = synthetic.rotation_only(10, seed=1)
     problem.upload(c.x1, c.x2)                                    # no per-match depths uploaded
