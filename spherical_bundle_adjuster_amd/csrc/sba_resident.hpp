@@ -62,10 +62,11 @@ inline void resident_write_command(ResidentRecord* rec, const double* payload, i
 }
 
 #if defined(__HIPCC__)
-// Device side, wave 0 only (all 64 lanes): wait for command `expect`, copy its payload to cmd_s[kResidentPayload] (LDS).
-// Returns the opcode, or RESIDENT_OP_QUIT with *end = RESIDENT_END_IDLE when no command arrived within idle_ticks.
-__device__ __forceinline__ int resident_wait_command(const ResidentRecord* __restrict__ rec, unsigned long long expect,
-                                                     unsigned long long idle_ticks, double* __restrict__ cmd_s, int* end) {
+// Device side, wave 0 only (all 64 lanes): wait for command `expect` and copy its payload to cmd_s[kResidentPayload] (LDS;
+// the opcode is cmd_s[0], to be read after the caller's barrier).  Returns true when the command arrived, false -- with
+// *end = RESIDENT_END_IDLE -- when none did within idle_ticks of the wall clock.
+__device__ __forceinline__ bool resident_wait_command(const ResidentRecord* __restrict__ rec, unsigned long long expect,
+                                                      unsigned long long idle_ticks, double* __restrict__ cmd_s, int* end) {
   const int lane = threadIdx.x & 63;
   const unsigned long long* words = reinterpret_cast<const unsigned long long*>(rec);
   const long long t0 = wall_clock64();
@@ -80,13 +81,13 @@ __device__ __forceinline__ int resident_wait_command(const ResidentRecord* __res
     if (static_cast<unsigned long long>(wall_clock64() - t0) > idle_ticks) break;
     __builtin_amdgcn_s_sleep(8);
   }
-  if (!got) { *end = RESIDENT_END_IDLE; return RESIDENT_OP_QUIT; }
+  if (!got) { *end = RESIDENT_END_IDLE; return false; }
   if ((lane & 7) != 7) {
     double d;
     __builtin_memcpy(&d, &v, sizeof(d));
     cmd_s[7 * (lane >> 3) + (lane & 7)] = d;
   }
-  return 0;   // opcode is cmd_s[0], read by the caller after the barrier
+  return true;
 }
 
 // Device side, wave 0: `count` (<= 24) result doubles from LDS -> mapped host pack, system-scope release, then `seq`.
