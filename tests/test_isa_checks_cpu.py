@@ -111,6 +111,18 @@ def test_profile_builds_keep_the_shape(batch_asm_profile):
         assert d and all(x == 0 for x in d), (name, d)
 
 
+def test_resident_kernel_barriers_are_block_uniform(batch_asm):
+    """resident_sweep_kernel (csrc/sba_resident.hpp: one block stays resident for a whole solve stage and polls a host
+    record) has the same loop shape by construction: two barriers around the one wave-0 region of a trip, the sweep's two,
+    all at loop depth 1, and one barrier after the loop at depth 0."""
+    funcs = _functions(batch_asm)
+    rs = {k: v for k, v in funcs.items() if "resident_sweep_kernel" in k}
+    assert len(rs) >= 20, len(rs)
+    for name, body in rs.items():
+        d = sorted(_barrier_depths(body))
+        assert d == [0, 1, 1, 1, 1], (name, d)
+
+
 def test_step_kernel_barriers_outside_loops(batch_asm):
     funcs = _functions(batch_asm)
     st = {k: v for k, v in funcs.items() if "batch_step_kernel" in k}
