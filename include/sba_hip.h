@@ -411,6 +411,17 @@ int sba_batch_step_is_fused(const sba_batch* b);
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,
                     const double* d2, const sba_lm_options* opt, sba_lm_summary* summaries, int* status);
 
+/* The d-only stage (spherical_bundle_adjuster.cpp:196-197, functor :1004-1063) for EVERY pair of the batch: what
+ * sba_problem_solve_depths does for one problem, per pair -- its own trust region, projected line search and convergence;
+ * the pairs advance in lock-step, one launch per pass of all unfinished pairs.  rot, tran: double[num_pairs][3] (frozen);
+ * needs per-match depths uploaded (the initial values) and refines them on the device, so that a following
+ * SBA_DEPTH_PER_MATCH sweep / solve sees them; d12_out (may be NULL): double[offsets[num_pairs]][2], indexed like the uploaded d12
+ * (the reference then takes d12_out[offsets[g]][0] and d12_out[offsets[g] + 1][0] as the pair's uniform depths of the rot /
+ * tran stages, .cpp:941-942).  summaries / status as sba_batch_solve.  One block per pair: batches with at least one
+ * pair per CU (SBA_ERR_UNSUPPORTED otherwise).                                                                  */
+int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, double lambda, double c,
+                           const sba_lm_options* opt, double* d12_out, sba_lm_summary* summaries, int* status);
+
 /* ---- callers / data formats either side of the path ------------------------------------- */
 /* pixel -> unit sphere (spherical_bundle_adjuster.cpp:271-298).  keypoints: n records of
  * `stride_bytes` bytes whose first two floats are pt.x, pt.y (cv::KeyPoint: stride 28).

@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 
+#include "sba_depth_solver.hpp"
 #include "sba_internal.hpp"
 #include "sba_lm.hpp"
 #include "sba_rotation.hpp"
@@ -54,6 +55,16 @@ struct sba_batch {
   sba::BatchLmIo* lm_io_host = nullptr;       // pinned + mapped: per-pair start point in, result + summary out (batch_lm_kernel)
   sba::BatchLmIo* lm_io_host_dev = nullptr;   // device-visible address of lm_io_host
   unsigned int* lm_ticket = nullptr;          // device: blocks of batch_lm_kernel that have delivered their record
+  std::vector<size_t> offsets;                // row offset of every pair in the caller's concatenated arrays (num_pairs + 1)
+  size_t plane_elems = 0;                     // elements per plane
+  // batched d-only stage (allocated on first use, kept while the batch lives)
+  double* depth_work = nullptr;               // 4 planes: candidate depths (2), Jacobi scaling (2)
+  sba::BatchDepthConst* depth_const_dev = nullptr;
+  sba::BatchDepthPass* depth_pass_host = nullptr;     // pinned + mapped
+  sba::BatchDepthPass* depth_pass_host_dev = nullptr;
+  double* depth_out_host = nullptr;           // pinned + mapped: [num_pairs][16] results, then the sequence word
+  double* depth_out_host_dev = nullptr;
+  unsigned long long depth_seq = 0;
 };
 
 namespace {
@@ -71,6 +82,12 @@ int free_batch_data(sba_batch* b) {
   if (b->packs_host) SBA_TRY_HIP(hipHostFree(b->packs_host));
   if (b->lm_io_host) SBA_TRY_HIP(hipHostFree(b->lm_io_host));
   if (b->lm_ticket) SBA_TRY_HIP(hipFree(b->lm_ticket));
+  if (b->depth_work) SBA_TRY_HIP(hipFree(b->depth_work));
+  if (b->depth_const_dev) SBA_TRY_HIP(hipFree(b->depth_const_dev));
+  if (b->depth_pass_host) SBA_TRY_HIP(hipHostFree(b->depth_pass_host));
+  if (b->depth_out_host) SBA_TRY_HIP(hipHostFree(b->depth_out_host));
+  b->depth_work = nullptr; b->depth_const_dev = nullptr; b->depth_pass_host = nullptr; b->depth_pass_host_dev = nullptr;
+  b->depth_out_host = nullptr; b->depth_out_host_dev = nullptr; b->depth_seq = 0; b->offsets.clear(); b->plane_elems = 0;
   b->lm_io_host = nullptr; b->lm_io_host_dev = nullptr; b->lm_ticket = nullptr;
   b->desc_dev = nullptr; b->params_dev = nullptr; b->state_host = nullptr; b->state_host_dev = nullptr;
   b->frames_dev = nullptr; b->partials = nullptr;
@@ -313,6 +330,8 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   }
   b->total_vecs = vec + 1;
   const size_t elems = b->total_vecs * ppt, esz = store == SBA_STORE_F64 ? 8 : 4;
+  b->plane_elems = elems;
+  b->offsets.assign(offsets, offsets + num_pairs + 1);
   for (int k = 0; k < 6; ++k) {
     const size_t lead = b->plane_stagger * static_cast<size_t>(k);
     SBA_TRY_HIP(hipMalloc(&b->plane_base[k], lead + elems * esz));
@@ -495,6 +514,113 @@ int sba_batch_step_is_fused(const sba_batch* b) {
   if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch");
   if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
   return step_is_fused(b) ? 1 : 0;
+}
+
+// The d-only stage for every pair of the batch (reference spherical_bundle_adjuster.cpp:196-197 once per pair): B independent
+// bounded trust-region problems -- own radius, own projected line search, own convergence -- advanced in LOCK-STEP: one
+// launch of batch_depth_step_kernel runs the next pass of every unfinished pair, the host feeds every pair's nine
+// reductions to that pair's DepthStageSolver (the very state machine of sba_problem_solve_depths).
+int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, double lambda, double c,
+                           const sba_lm_options* opt, double* d12_out, sba_lm_summary* summaries, int* status) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  SBA_REFUSE_POISONED(b);
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  const int B = b->num_pairs;
+  if (B == 0) return SBA_OK;
+  if (!rot || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "rot/tran must not be null");
+  if (!b->has_d12) return sba::set_error(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
+  if (b->bpp != 1)
+    return sba::set_error(SBA_ERR_UNSUPPORTED, "the batched d-only stage runs one block per pair (batches of at least one pair "
+                                               "per CU); this batch spreads a pair over %d blocks", b->bpp);
+  if (!b->publish) return sba::set_error(SBA_ERR_UNSUPPORTED, "the batched d-only stage needs host-mapped publication (SBA_PUBLISH=0 is set)");
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  sba_lm_options o;
+  if (opt) o = *opt; else sba::lm_default_options(&o);
+  const auto t_start = std::chrono::steady_clock::now();
+  const size_t elems = b->plane_elems;
+  if (!b->depth_work) {
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->depth_work), 4 * elems * sizeof(double)));
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->depth_const_dev), sizeof(sba::BatchDepthConst) * B));
+    SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->depth_pass_host), sizeof(sba::BatchDepthPass) * B,
+                              hipHostMallocMapped | hipHostMallocCoherent));
+    SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->depth_pass_host_dev), b->depth_pass_host, 0));
+    SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->depth_out_host), sizeof(double) * (static_cast<size_t>(B) * sba::DEPTH_ROW + 8),
+                              hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(b->depth_out_host, 0, sizeof(double) * (static_cast<size_t>(B) * sba::DEPTH_ROW + 8));
+    SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->depth_out_host_dev), b->depth_out_host, 0));
+    b->depth_seq = 0;
+  }
+  // candidate + scaling planes start zeroed: a candidate plane becomes a pair's depth plane when a step is accepted, and its
+  // padding must be zeros like the uploaded planes'
+  SBA_TRY_HIP(hipMemsetAsync(b->depth_work, 0, 4 * elems * sizeof(double), b->stream));
+  double *w1 = b->depth_work, *w2 = w1 + elems, *sc1 = w1 + 2 * elems, *sc2 = w1 + 3 * elems;
+  std::vector<sba::BatchDepthConst> cst(B);
+  for (int g = 0; g < B; ++g) {
+    for (int a = 0; a < 3; ++a)
+      if (!std::isfinite(rot[3 * g + a]) || !std::isfinite(tran[3 * g + a])) return sba::set_error(SBA_ERR_INVALID_ARG, "non-finite rot/tran of pair %d", g);
+    sba::rotation_and_derivatives(rot + 3 * g, cst[g].R, nullptr);
+    for (int a = 0; a < 3; ++a) cst[g].t[a] = tran[3 * g + a];
+  }
+  SBA_TRY_HIP(hipMemcpyAsync(b->depth_const_dev, cst.data(), sizeof(sba::BatchDepthConst) * B, hipMemcpyHostToDevice, b->stream));
+  { const int _rc = sba::stream_wait(b->stream, "batched d-only set-up", &b->poisoned); if (_rc) return _rc; }   // cst goes out of use
+
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
+  pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  std::vector<sba::DepthStageSolver> solver(B);
+  std::vector<unsigned char> flip(B, 0), active(B, 1);
+  for (int g = 0; g < B; ++g) solver[g].start(o);
+  int remaining = B;
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->depth_out_host + static_cast<size_t>(B) * sba::DEPTH_ROW);
+  while (remaining > 0) {
+    for (int g = 0; g < B; ++g) {
+      sba::BatchDepthPass& ps = b->depth_pass_host[g];
+      if (!active[g]) { ps = sba::BatchDepthPass{1.0, 1.0, 0ull, 0u, 0u}; continue; }
+      const sba::DepthPassRequest& rq = solver[g].request();
+      ps.radius = rq.radius; ps.alpha = rq.alpha; ps.n = b->n[g]; ps.pad_ = 0;
+      ps.flags = (rq.first ? 1u : 0u) | (rq.keep_diagonal ? 2u : 0u) | (o.jacobi_scaling ? 4u : 0u) | (flip[g] ? 8u : 0u);
+    }
+    const unsigned long long seq = ++b->depth_seq;
+    SBA_TRY_HIP(sba::launch_batch_depth_step(b->store, pl, b->desc_dev, b->depth_const_dev, b->depth_pass_host_dev, B, lambda, c,
+                                             o.min_lm_diagonal, o.max_lm_diagonal, b->dplane[0], b->dplane[1], w1, w2, sc1, sc2,
+                                             b->depth_out_host_dev, b->lm_ticket, seq, b->stream));
+    const int wrc = sba::wait_for_sequence(flag, seq, b->stream, "batched d-only pass", &b->poisoned);
+    if (wrc) return wrc;
+    for (int g = 0; g < B; ++g) {
+      if (!active[g]) continue;
+      solver[g].feed(b->depth_out_host + static_cast<size_t>(g) * sba::DEPTH_ROW);
+      if (solver[g].take_candidate()) flip[g] ^= 1;
+      if (solver[g].done()) { active[g] = 0; --remaining; }
+    }
+  }
+  // results back into the batch's own depth planes (pairs that ended on an odd number of accepted steps), and out to the host
+  sba::DeviceBuffer flip_dev(&b->poisoned), off_dev(&b->poisoned), out_dev(&b->poisoned);
+  SBA_TRY_HIP(flip_dev.alloc(static_cast<size_t>(B)));
+  SBA_TRY_HIP(hipMemcpyAsync(flip_dev.ptr, flip.data(), static_cast<size_t>(B), hipMemcpyHostToDevice, b->stream));
+  // d12_out is indexed like the uploaded arrays (pair g at offsets[g]); the device buffer holds rows offsets[0] .. offsets[B]
+  const size_t base = b->offsets.empty() ? 0 : b->offsets.front();
+  std::vector<unsigned long long> off64;
+  for (size_t v : b->offsets) off64.push_back(v - base);
+  const size_t total = b->offsets.empty() ? 0 : b->offsets.back() - base;
+  if (d12_out && total > 0) {
+    SBA_TRY_HIP(off_dev.alloc(sizeof(unsigned long long) * off64.size()));
+    SBA_TRY_HIP(hipMemcpyAsync(off_dev.ptr, off64.data(), sizeof(unsigned long long) * off64.size(), hipMemcpyHostToDevice, b->stream));
+    SBA_TRY_HIP(out_dev.alloc(2 * total * sizeof(double)));
+  }
+  SBA_TRY_HIP(sba::launch_batch_depth_finish(b->store, b->desc_dev, flip_dev.as<unsigned char>(), B, b->dplane[0], b->dplane[1], w1, w2,
+                                             off_dev.as<unsigned long long>(), d12_out && total > 0 ? out_dev.as<double>() : nullptr, b->stream));
+  if (d12_out && total > 0)
+    SBA_TRY_HIP(hipMemcpyAsync(d12_out + 2 * base, out_dev.ptr, 2 * total * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  { const int _rc = sba::stream_wait(b->stream, "batched d-only stage", &b->poisoned); if (_rc) return _rc; }
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  int failures = 0;
+  for (int g = 0; g < B; ++g) {
+    if (summaries) { summaries[g] = solver[g].summary(); summaries[g].seconds_total = seconds; }   // wall clock of the whole batch
+    if (status) status[g] = solver[g].status();
+    if (solver[g].status() != SBA_OK) ++failures;
+  }
+  if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed in the d-only stage (see per-pair status)", failures, B);
+  return SBA_OK;
 }
 
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,

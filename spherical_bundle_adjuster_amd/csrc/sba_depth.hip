@@ -82,24 +82,37 @@ struct DepthRegs {
 // next ones -- would two steps ahead (+40 VGPRs: 227, still two waves per SIMD) feed the memory system better?  Measured:
 // no -- 177.4 us per pass against 169.1 us (rocprofv3 averages over 54 launches, same box; profiles/r03_depth_ahead.log).
 // One step ahead is the default; SBA_DEPTH_AHEAD=2 keeps the variant reachable.
-template <typename ST, int AHEAD>
+// MAP: logical pair-of-matches index -> index into the planes (identity for a single problem; the batch's pair layout,
+// contiguous or interleaved tiles, for a pair of a batch).
+struct IdentityMap { __device__ __forceinline__ size_t operator()(size_t pr) const { return pr; } };
+template <typename ST> struct BatchPairMap;
+template <> struct BatchPairMap<double> {      // f64 planes: a 16-byte vector holds one pair of matches
+  PairDesc d;
+  __device__ __forceinline__ size_t operator()(size_t pr) const { return pair_vector(d, pr); }
+};
+template <> struct BatchPairMap<float> {       // f32 coordinate planes: a vector holds two pairs; the f64 depth planes follow it
+  PairDesc d;
+  __device__ __forceinline__ size_t operator()(size_t pr) const { return 2 * pair_vector(d, pr >> 1) + (pr & 1); }
+};
+
+template <typename ST, int AHEAD, typename MAP = IdentityMap>
 __device__ __forceinline__ void depth_stream(const Planes& pl, const double* __restrict__ d1, const double* __restrict__ d2,
                                              double* __restrict__ c1, double* __restrict__ c2, double* __restrict__ sc1,
                                              double* __restrict__ sc2, const DepthParams& P, size_t pr, size_t stride,
-                                             double r[DEPTH_OUT_COUNT]) {
+                                             double r[DEPTH_OUT_COUNT], const MAP map = MAP()) {
   static_assert(AHEAD == 1 || AHEAD == 2, "one or two steps of loads in flight");
   const size_t npairs = (P.n + 1) / 2;     // the planes are zero-padded to a whole vector (+ one spare)
   const bool load_scale = !P.first_iteration;
   double cost = 0, model = 0, cand_cost = 0, step2 = 0, x2n = 0, gdelta = 0, cand_gdelta = 0, gmax = 0, dmax = 0;
   DepthRegs<ST> cur, nxt, nx2;
-  if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, load_scale, pr);
-  if (AHEAD == 2 && pr + stride < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, pr + stride);
+  if (pr < npairs) cur.load(pl, d1, d2, sc1, sc2, load_scale, map(pr));
+  if (AHEAD == 2 && pr + stride < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, map(pr + stride));
   while (pr < npairs) {
-    const size_t pn = pr + stride;
+    const size_t pn = pr + stride, q = map(pr);           // q: where this lane's two matches sit in the planes
     if (AHEAD == 2) {
-      if (pn + stride < npairs) nx2.load(pl, d1, d2, sc1, sc2, load_scale, pn + stride);
+      if (pn + stride < npairs) nx2.load(pl, d1, d2, sc1, sc2, load_scale, map(pn + stride));
     } else {
-      if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, pn);
+      if (pn < npairs) nxt.load(pl, d1, d2, sc1, sc2, load_scale, map(pn));
     }
     double NA[2], NB[2];
 #pragma unroll
@@ -160,9 +173,9 @@ __device__ __forceinline__ void depth_stream(const Planes& pl, const double* __r
         NA[h] = 0.0; NB[h] = 0.0;   // keep the padding zero
       }
     }
-    if (P.stream_stores) { store_pair_stream(c1, pr, NA[0], NA[1]); store_pair_stream(c2, pr, NB[0], NB[1]); }
-    else { store_pair_f64(c1, pr, NA[0], NA[1]); store_pair_f64(c2, pr, NB[0], NB[1]); }
-    if (P.first_iteration) { store_pair_f64(sc1, pr, cur.S1[0], cur.S1[1]); store_pair_f64(sc2, pr, cur.S2[0], cur.S2[1]); }
+    if (P.stream_stores) { store_pair_stream(c1, q, NA[0], NA[1]); store_pair_stream(c2, q, NB[0], NB[1]); }
+    else { store_pair_f64(c1, q, NA[0], NA[1]); store_pair_f64(c2, q, NB[0], NB[1]); }
+    if (P.first_iteration) { store_pair_f64(sc1, q, cur.S1[0], cur.S1[1]); store_pair_f64(sc2, q, cur.S2[0], cur.S2[1]); }
     cur = nxt;
     if (AHEAD == 2) nxt = nx2;
     pr = pn;
@@ -173,6 +186,7 @@ static_assert(DEPTH_OUT_COUNT == 9 && DEPTH_OUT_SUMS == 7, "depth_stream fills s
 
 // Block-level fold of the per-lane partials: lanes by butterfly, the four waves in wave order; res[0..8] valid on
 // threads < DEPTH_OUT_COUNT after the call (which contains one barrier).
+template <int NW = 4>
 __device__ __forceinline__ double depth_block_fold(const double r[DEPTH_OUT_COUNT], double (*red)[DEPTH_OUT_COUNT]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -185,7 +199,7 @@ __device__ __forceinline__ double depth_block_fold(const double r[DEPTH_OUT_COUN
   if (threadIdx.x < DEPTH_OUT_COUNT) {
     const bool is_max = threadIdx.x >= DEPTH_OUT_SUMS;
     s = red[0][threadIdx.x];
-    for (int wv = 1; wv < 4; ++wv) s = is_max ? fmax(s, red[wv][threadIdx.x]) : s + red[wv][threadIdx.x];
+    for (int wv = 1; wv < NW; ++wv) s = is_max ? fmax(s, red[wv][threadIdx.x]) : s + red[wv][threadIdx.x];
   }
   return s;
 }
@@ -268,6 +282,86 @@ __global__ __launch_bounds__(256, 2) void resident_depth_kernel(Planes pl, unsig
   }
 }
 
+// ---- batched d-only stage (config C5: the first stage of solve_problem for every pair of a batch) --------------------------------
+// One 512-thread block per pair (8 waves per CU, like two blocks of the single-problem kernel): thread 0 reads the pair's
+// pass record (radius, step size, flags) from mapped host memory, the block runs the pair's pass with the pair's own
+// rotation / translation, folds the nine reductions and publishes them to mapped host memory; the block that delivers the
+// last pair stores the sequence word the host polls (as batch_step_kernel).  Every pair has its own trust region, line search
+// and convergence -- B independent DepthStageSolvers advance in lock-step on the host (sba_batch.cpp).  flags: bit 0 first
+// pass (store the Jacobi scaling), bit 1 keep the diagonal, bit 2 jacobi scaling on, bit 3 `flip` (the pair's current
+// depths are in the work planes, its candidates go to the batch's depth planes); n == 0: the pair is finished, skip it.
+template <typename ST>
+__global__ __launch_bounds__(512, 2) void batch_depth_step_kernel(Planes pl, const PairDesc* __restrict__ desc,
+                                                                 const BatchDepthConst* __restrict__ cst,
+                                                                 const BatchDepthPass* __restrict__ pass, double lambda, double c,
+                                                                 double min_diagonal, double max_diagonal,
+                                                                 double* __restrict__ a1, double* __restrict__ a2,
+                                                                 double* __restrict__ b1, double* __restrict__ b2,
+                                                                 double* __restrict__ sc1, double* __restrict__ sc2,
+                                                                 double* __restrict__ out_host, unsigned int* __restrict__ ticket,
+                                                                 unsigned long long seq) {
+  __shared__ double red[8][DEPTH_OUT_COUNT];
+  __shared__ BatchDepthPass pass_s;
+  const unsigned pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) pass_s = pass[pair];
+  __syncthreads();
+  const BatchDepthPass ps = pass_s;
+  const PairDesc dsc = desc[pair];
+  const size_t n = ps.n < dsc.n ? ps.n : dsc.n;          // never past the pair's own matches, whatever the record says
+  double s = 0.0;
+  if (n > 0) {
+    DepthParams P;
+    const BatchDepthConst k = cst[pair];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) P.R[i] = k.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.t[i] = k.t[i];
+    P.lambda = lambda; P.c = c; P.radius = ps.radius; P.inv_radius = 1.0 / ps.radius;
+    P.min_diagonal = min_diagonal; P.max_diagonal = max_diagonal; P.alpha = ps.alpha;
+    P.first_iteration = ps.flags & 1; P.reuse_diagonal = (ps.flags >> 1) & 1; P.jacobi_scaling = (ps.flags >> 2) & 1;
+    P.stream_stores = 0; P.n = n;
+    const bool flip = (ps.flags >> 3) & 1;
+    double r[DEPTH_OUT_COUNT];
+    depth_stream<ST, 1, BatchPairMap<ST>>(pl, flip ? b1 : a1, flip ? b2 : a2, flip ? a1 : b1, flip ? a2 : b2, sc1, sc2, P,
+                                          static_cast<size_t>(tid), 512, r, BatchPairMap<ST>{dsc});
+    s = depth_block_fold<8>(r, red);
+  }
+  if (tid >= 64) return;                  // wave 0 finishes alone
+  if (tid < DEPTH_OUT_COUNT) host_store(out_host + static_cast<size_t>(pair) * DEPTH_ROW + tid, s);
+  host_release();
+  if (tid == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(out_host + static_cast<size_t>(gridDim.x) * DEPTH_ROW), seq,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// After the stage: pairs whose result sits in the work planes (flip) are copied back into the batch's depth planes, and --
+// when out != nullptr -- every pair's depths are written in init_d layout (double[total][2], pair g at offsets[g]).
+template <typename ST>
+__global__ __launch_bounds__(256) void batch_depth_finish_kernel(const PairDesc* __restrict__ desc, const unsigned char* __restrict__ flip,
+                                                                double* __restrict__ a1, double* __restrict__ a2,
+                                                                const double* __restrict__ b1, const double* __restrict__ b2,
+                                                                const unsigned long long* __restrict__ offsets, double* __restrict__ out) {
+  const unsigned pair = blockIdx.x;
+  const PairDesc dsc = desc[pair];
+  const BatchPairMap<ST> map{dsc};
+  const bool fl = flip[pair] != 0;
+  const size_t npairs = (dsc.n + 1) / 2;
+  for (size_t pr = threadIdx.x; pr < npairs; pr += 256) {
+    const size_t q = map(pr);
+    double2 u = reinterpret_cast<const double2*>(fl ? b1 : a1)[q], v = reinterpret_cast<const double2*>(fl ? b2 : a2)[q];
+    if (fl) { reinterpret_cast<double2*>(a1)[q] = u; reinterpret_cast<double2*>(a2)[q] = v; }
+    if (out) {
+      const size_t i = offsets[pair] + 2 * pr;
+      reinterpret_cast<double2*>(out)[i] = make_double2(u.x, v.x);
+      if (2 * pr + 1 < dsc.n) reinterpret_cast<double2*>(out)[i + 1] = make_double2(u.y, v.y);
+    }
+  }
+}
+
 // [nblocks][16] -> out[9]: sums of slots 0..6 and the maxima of slots 7, 8, in a fixed order.
 // With host_out (mapped pinned memory) the nine results are also published to the host: stores, system-scope release,
 // then the sequence number in host_out[24] -- the host polls that word (same protocol as finalize_kernel).
@@ -343,6 +437,33 @@ hipError_t launch_resident_depth(int store, const Planes& pl, size_t n, double* 
   else
     hipLaunchKernelGGL((resident_depth_kernel<float>), dim3(1), dim3(256), 0, stream, pl, static_cast<unsigned long long>(n), a1, a2,
                        b1, b2, sc1, sc2, rec_dev, host_pack_dev, first_cmd_seq, first_pack_seq, idle_ticks);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_depth_step(int store, const Planes& pl, const PairDesc* desc, const BatchDepthConst* cst,
+                                   const BatchDepthPass* pass_host_dev, int num_pairs, double lambda, double c, double min_diagonal,
+                                   double max_diagonal, double* a1, double* a2, double* b1, double* b2, double* sc1, double* sc2,
+                                   double* out_host_dev, unsigned int* ticket, unsigned long long seq, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  if (store == 0)
+    hipLaunchKernelGGL((batch_depth_step_kernel<double>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, pass_host_dev, lambda, c,
+                       min_diagonal, max_diagonal, a1, a2, b1, b2, sc1, sc2, out_host_dev, ticket, seq);
+  else
+    hipLaunchKernelGGL((batch_depth_step_kernel<float>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, pass_host_dev, lambda, c,
+                       min_diagonal, max_diagonal, a1, a2, b1, b2, sc1, sc2, out_host_dev, ticket, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_depth_finish(int store, const PairDesc* desc, const unsigned char* flip_dev, int num_pairs, double* a1,
+                                     double* a2, const double* b1, const double* b2, const unsigned long long* offsets_dev,
+                                     double* out_dev, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  if (store == 0)
+    hipLaunchKernelGGL((batch_depth_finish_kernel<double>), dim3(num_pairs), dim3(256), 0, stream, desc, flip_dev, a1, a2, b1, b2,
+                       offsets_dev, out_dev);
+  else
+    hipLaunchKernelGGL((batch_depth_finish_kernel<float>), dim3(num_pairs), dim3(256), 0, stream, desc, flip_dev, a1, a2, b1, b2,
+                       offsets_dev, out_dev);
   return hipGetLastError();
 }
 

@@ -205,6 +205,24 @@ hipError_t launch_depth_step(int store, const Planes& pl, const double* d1, cons
                              const DepthParams& prm, double* partials, int grid, double* out, double* host_out,
                              unsigned long long seq, int gather_slot, hipStream_t stream);
 
+// Batched d-only stage (one 512-thread block per pair; sba_depth.hip).  BatchDepthConst: the pair's frozen rotation matrix
+// and translation (device array, set once per solve).  BatchDepthPass: what the host hands over per pair and pass (mapped
+// pinned host memory, 32 B): radius and step size of the pass, flags (bit 0 first pass, 1 keep diagonal, 2 jacobi scaling,
+// 3 flip: current depths in the work planes), n = matches taking part (0: pair finished).  Results: out_host[pair][16]
+// (DEPTH_OUT_* slots) in mapped host memory, then `seq` at out_host[num_pairs * 16].
+struct BatchDepthConst { double R[9]; double t[3]; };
+struct BatchDepthPass { double radius, alpha; unsigned long long n; unsigned int flags, pad_; };
+static_assert(sizeof(BatchDepthPass) == 32, "BatchDepthPass layout");
+hipError_t launch_batch_depth_step(int store, const Planes& pl, const PairDesc* desc, const BatchDepthConst* cst,
+                                   const BatchDepthPass* pass_host_dev, int num_pairs, double lambda, double c, double min_diagonal,
+                                   double max_diagonal, double* a1, double* a2, double* b1, double* b2, double* sc1, double* sc2,
+                                   double* out_host_dev, unsigned int* ticket, unsigned long long seq, hipStream_t stream);
+// pairs with flip_dev[pair] != 0: work planes -> the batch's depth planes; out_dev != nullptr: every pair's depths in init_d
+// layout at offsets_dev[pair]
+hipError_t launch_batch_depth_finish(int store, const PairDesc* desc, const unsigned char* flip_dev, int num_pairs, double* a1,
+                                     double* a2, const double* b1, const double* b2, const unsigned long long* offsets_dev,
+                                     double* out_dev, hipStream_t stream);
+
 // 8-point initial guess, device part (.cpp:53-68): A^T A of the kron(left, right) rows for 64 interleaved groups.
 // groups_dev: [64][45]; partials: [grid][45][64] scratch.
 hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double* partials, int grid,

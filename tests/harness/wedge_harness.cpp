@@ -110,6 +110,13 @@ hipError_t launch_depth_step(int, const Planes&, const double*, const double*, d
   publish(host, 24, seq); return hipSuccess;
 }
 hipError_t launch_epipolar_moments(int, const Planes&, size_t, double*, int, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_depth_step(int, const Planes&, const PairDesc*, const BatchDepthConst*, const BatchDepthPass*, int np, double, double,
+                                   double, double, double*, double*, double*, double*, double*, double*, double* host, unsigned int*,
+                                   unsigned long long seq, hipStream_t) {
+  publish(host, static_cast<size_t>(DEPTH_ROW) * np, seq); return hipSuccess;
+}
+hipError_t launch_batch_depth_finish(int, const PairDesc*, const unsigned char*, int, double*, double*, const double*, const double*,
+                                     const unsigned long long*, double*, hipStream_t) { return hipSuccess; }
 // ---- the resident kernels, emulated by a host thread that speaks the device side of the protocol (sba_resident.hpp) -------
 // Same record decoding as resident_wait_command (check word per line), same publication order as resident_publish, same
 // ends (QUIT command, idle time-out, trip budget).  The "sweep" it answers with is a fixed function of the command's

@@ -77,6 +77,54 @@ def test_interleaved_pair_layout_is_bit_identical_to_the_contiguous_one(sizes, s
     assert [q.num_iterations for q in got["0"][1][2]] == [q.num_iterations for q in got["1"][1][2]]
 
 
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("layout", ["0", "1"], ids=["contiguous", "interleaved"])
+def test_batch_depth_stage_matches_single_problem_stages(oracle, store, layout, monkeypatch):
+    """sba_batch_solve_depths: the d-only stage (reference .cpp:196-197, :1004-1063) for every pair of a batch -- B
+    independent bounded problems, each with its own trust region, projected line search and convergence, advanced in
+    lock-step by one launch per pass.  Per pair it must do what sba_problem_solve_depths does for that pair alone: same
+    iteration / accepted-step / contraction counts and termination, depths to 1e-9 -- ragged pairs, an empty one, a
+    1-match one, pairs whose full step fails Armijo (start d = 1) next to pairs that converge at once -- and the oracle's
+    numbers; the refined depths must be the ones a following per-match sweep sees."""
+    monkeypatch.setenv("SBA_BATCH_INTERLEAVE", layout)
+    sizes = [500, 0, 257, 1, 300, 64, 1023, 2] + [150 + 7 * g for g in range(40)]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=6)                 # seed 6, n = 500: one contraction to a = 0.49
+    B = len(sizes)
+    start = np.ones_like(d12)
+    start[off[4]:off[5]] = 3.0                                         # one pair starts elsewhere
+    rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, start, store=store)
+        assert b.blocks_per_pair == 1
+        d, sums, status = b.solve_depths(rot, tran)
+        assert (status == 0).all() and d.shape == start.shape
+        packs = b.eval(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)     # the batch's planes hold the refined depths
+        d_again, sums2, _ = b.solve_depths(rot, tran)                              # ... and a second stage starts from them
+    contractions = 0
+    for g, c in enumerate(cs):
+        n = sizes[g]
+        lo, hi = int(off[g]), int(off[g + 1])
+        if n == 0:
+            assert sums[g].termination == "CONVERGENCE_GRADIENT" and sums[g].num_iterations == 0
+            continue
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, start[lo:hi], store=store)
+            d1, s1 = p.solve_depths(c.rot_init, c.tran_init)
+            ref_pack = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        assert (sums[g].num_iterations, sums[g].num_successful_steps, sums[g].num_line_search_steps, sums[g].termination) == \
+            (s1.num_iterations, s1.num_successful_steps, s1.num_line_search_steps, s1.termination), (g, n)
+        assert np.abs(d[lo:hi] - d1).max() <= 1e-9 * max(1.0, np.abs(d1).max()), (g, n)
+        assert np.abs(packs[g] - ref_pack).max() <= 1e-9 * max(np.abs(ref_pack).max(), 1e-300), (g, n)
+        assert sums2[g].num_iterations <= 1 or sums2[g].final_cost <= sums[g].final_cost * (1 + 1e-12)
+        contractions += sums[g].num_line_search_steps
+        if store == api.STORE_F64 and g in (0, 2, 4, 6):
+            dref, sref, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, start[lo:hi])
+            assert rc == 0 and sums[g].num_iterations == sref.num_iterations and sums[g].num_line_search_steps == sref.num_line_search_steps
+            assert np.abs(d[lo:hi] - dref).max() <= 1e-7 * max(1.0, np.abs(dref).max())
+    assert contractions >= 1                                            # the batch really exercised the line search
+    assert len({s_.num_evaluations for s_, n in zip(sums, sizes) if n > 0}) > 1      # ... and pairs finished at different passes
+
+
 def test_batch_solve_matches_single_problem_solves(oracle):
     sizes = [4000, 0, 2500, 3333, 1, 5000]
     cs, off, x1, x2, d12 = _make_pairs(sizes)
