@@ -417,8 +417,8 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
  * needs per-match depths uploaded (the initial values) and refines them on the device, so that a following
  * SBA_DEPTH_PER_MATCH sweep / solve sees them; d12_out (may be NULL): double[offsets[num_pairs]][2], indexed like the uploaded d12
  * (the reference then takes d12_out[offsets[g]][0] and d12_out[offsets[g] + 1][0] as the pair's uniform depths of the rot /
- * tran stages, .cpp:941-942).  summaries / status as sba_batch_solve.  One block per pair: batches with at least one
- * pair per CU (SBA_ERR_UNSUPPORTED otherwise).                                                                  */
+ * tran stages, .cpp:941-942).  summaries / status as sba_batch_solve.  One 512-thread block per pair and pass: made for
+ * batches of many pairs (config C5); a batch of a few huge pairs is served, but by as many CUs as it has pairs.      */
 int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, double lambda, double c,
                            const sba_lm_options* opt, double* d12_out, sba_lm_summary* summaries, int* status);
 

@@ -529,9 +529,6 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
   if (B == 0) return SBA_OK;
   if (!rot || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "rot/tran must not be null");
   if (!b->has_d12) return sba::set_error(SBA_ERR_INVALID_ARG, "the d-only stage needs per-match depths uploaded");
-  if (b->bpp != 1)
-    return sba::set_error(SBA_ERR_UNSUPPORTED, "the batched d-only stage runs one block per pair (batches of at least one pair "
-                                               "per CU); this batch spreads a pair over %d blocks", b->bpp);
   if (!b->publish) return sba::set_error(SBA_ERR_UNSUPPORTED, "the batched d-only stage needs host-mapped publication (SBA_PUBLISH=0 is set)");
   SBA_TRY_HIP(hipSetDevice(b->device));
   sba_lm_options o;

@@ -95,7 +95,6 @@ def test_batch_depth_stage_matches_single_problem_stages(oracle, store, layout, 
     rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
     with api.Batch(0) as b:
         b.upload(x1, x2, off, start, store=store)
-        assert b.blocks_per_pair == 1
         d, sums, status = b.solve_depths(rot, tran)
         assert (status == 0).all() and d.shape == start.shape
         packs = b.eval(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)     # the batch's planes hold the refined depths
