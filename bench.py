@@ -240,6 +240,25 @@ def run_c5(a):
         rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
         lm_s = time.perf_counter() - t_lm
         bpp = b.blocks_per_pair
+        # the d-only stage of every pair (the first stage of solve_problem, reference .cpp:196-197), all pairs in lock-step
+        depth = None
+        try:
+            d0 = np.full((B * n, 2), 5.0)
+            b.upload(x1, x2, off, d0)
+            b.solve_depths(rot0, tran0)                                  # first call: scratch allocations
+            b.upload(x1, x2, off, d0)
+            t_d = time.perf_counter()
+            _, dsums, dstatus = b.solve_depths(rot0, tran0)
+            d_s = time.perf_counter() - t_d
+            passes = max(q.num_evaluations for q in dsums)
+            depth = {"seconds": d_s, "passes_lock_step": passes, "iterations_min_max": [min(q.num_iterations for q in dsums), max(q.num_iterations for q in dsums)],
+                     "us_per_pass": d_s / max(passes, 1) * 1e6, "all_converged": bool((dstatus == 0).all() and all(q.termination.startswith("CONV") for q in dsums)),
+                     "algorithmic_bytes_per_pass": B * n * 96,
+                     "frac_if_all_pairs_active": B * n * 96 / (d_s / max(passes, 1)) / 1e9 / HBM_PEAK_GBPS,
+                     "what": "sba_batch_solve_depths: every pair's bounded d-only problem (own trust region, line search, convergence), one "
+                             "launch per pass of all unfinished pairs, start d = 5"}
+        except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the line down
+            depth = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     remap = None
     if rank == 0 and a.frames > 0:
         # "equi2cube remap on GPU": device-resident frames, 3840x1920 -> S = 600 strip, 6 B per output pixel
@@ -297,6 +316,7 @@ def run_c5(a):
                    "max_iterations": max(s_.num_iterations for s_ in sums),
                    "all_converged": bool((status == 0).all() and all(s_.termination.startswith("CONV") for s_ in sums)),
                    "max_rot_err_rad": float(max(np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)))},
+            "depth_stage": depth,
             "equi2cube": remap, "upload_s": upload_s,
         }
         if not a.no_cpu_baseline and world == 1:
@@ -509,7 +529,7 @@ def c5_leg(steps: int, warmup: int):
                 "steps": d["steps"], "warmup": d["warmup"], "step": d["config"]["step"],
                 "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch",
                                                     "sweep_kernel_alone")},
-                "lm": d["lm"], "equi2cube": d["equi2cube"],
+                "lm": d["lm"], "depth_stage": d.get("depth_stage"), "equi2cube": d["equi2cube"],
                 "what": "child run of `python bench.py --workload c5` (same K / W) after the timed region"}
     except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}
