@@ -467,18 +467,18 @@ class Batch:
         return rot, tran, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
 
     def solve_depths(self, rot, tran, lam: float = 1.0, c: float = 1.0, options: cabi.LmOptions | None = None,
-                     total_matches: int | None = None):
+                     total_matches: int | None = None, want_depths: bool = True):
         """The d-only stage for every pair (its own trust region / line search / convergence each), in lock-step.
         Returns (d12 (offsets[-1], 2) indexed like the uploaded depths, [SolveSummary], status (B,))."""
         rot = _f64(rot).reshape(self.num_pairs, 3)
         tran = _f64(tran).reshape(self.num_pairs, 3)
         opt = options if options is not None else default_lm_options()
         total = int(self._total) if total_matches is None else int(total_matches)
-        d12 = np.zeros((total, 2))
+        d12 = np.zeros((total, 2)) if want_depths else None           # None: the refined depths stay on the device only
         sums = (cabi.LmSummary * max(self.num_pairs, 1))()
         status = np.zeros(max(self.num_pairs, 1), dtype=np.int32)
         cabi.check(self._lib, self._lib.sba_batch_solve_depths(self._h, _dptr(rot), _dptr(tran), lam, c, C.byref(opt),
-                                                               d12.ctypes.data_as(C.c_void_p), sums,
+                                                               d12.ctypes.data_as(C.c_void_p) if want_depths else None, sums,
                                                                status.ctypes.data_as(C.POINTER(C.c_int))))
         return d12, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
 
