@@ -240,7 +240,8 @@ def run_c5(a):
         rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
         lm_s = time.perf_counter() - t_lm
         bpp = b.blocks_per_pair
-        # the d-only stage of every pair (the first stage of solve_problem, reference .cpp:196-197), all pairs in lock-step
+        # the d-only stage of every pair (the first stage of solve_problem, reference .cpp:196-197): one launch, one solver per
+        # pair on the device (SBA_BATCH_DEVICE_DEPTH=0: host solvers in lock-step, one launch per pass)
         depth = None
         try:
             d0 = np.full((B * n, 2), 5.0)
@@ -252,13 +253,17 @@ def run_c5(a):
             d_s = time.perf_counter() - t_d
             passes = max(q.num_evaluations for q in dsums)
             pair_passes = sum(q.num_evaluations for q in dsums)         # a pair leaves the lock-step when it has converged
-            depth = {"seconds": d_s, "passes_lock_step": passes, "pair_passes": pair_passes,
+            one_launch = os.environ.get("SBA_BATCH_DEVICE_DEPTH", "1") != "0"
+            depth = {"seconds": d_s, "driver": "one launch, per-pair solvers on the device" if one_launch else "host lock-step, one launch per pass",
+                     "passes_longest_pair": passes, "pair_passes": pair_passes,
                      "iterations_min_max": [min(q.num_iterations for q in dsums), max(q.num_iterations for q in dsums)],
                      "us_per_pass": d_s / max(passes, 1) * 1e6, "all_converged": bool((dstatus == 0).all() and all(q.termination.startswith("CONV") for q in dsums)),
                      "algorithmic_bytes": pair_passes * n * 96,
                      "frac": pair_passes * n * 96 / d_s / 1e9 / HBM_PEAK_GBPS,
-                     "what": "sba_batch_solve_depths: every pair's bounded d-only problem (own trust region, line search, convergence), one "
-                             "launch per pass of all unfinished pairs, start d = 5"}
+                     "ideal_balanced_s": pair_passes * n * 96 / (0.72 * HBM_PEAK_GBPS * 1e9),
+                     "what": "sba_batch_solve_depths: every pair's bounded d-only problem (own trust region, line search, convergence), "
+                             "start d = 5; the time is the LONGEST pair's passes on its one CU (pairs need 9-36 iterations), "
+                             "ideal_balanced_s = the same pair-passes spread evenly at the d-only kernel's own 0.72 of peak"}
         except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the line down
             depth = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     remap = None

@@ -564,11 +564,52 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
   sba::Planes pl;
   for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
   pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  // d12_out is indexed like the uploaded arrays (pair g at offsets[g]); the device buffer holds rows offsets[0] .. offsets[B]
+  const size_t base = b->offsets.empty() ? 0 : b->offsets.front();
+  std::vector<unsigned long long> off64;
+  for (size_t v : b->offsets) off64.push_back(v - base);
+  const size_t total = b->offsets.empty() ? 0 : b->offsets.back() - base;
+  sba::DeviceBuffer flip_dev(&b->poisoned), off_dev(&b->poisoned), out_dev(&b->poisoned);
+  const bool want_out = d12_out && total > 0;
+  if (want_out) {
+    SBA_TRY_HIP(off_dev.alloc(sizeof(unsigned long long) * off64.size()));
+    SBA_TRY_HIP(hipMemcpyAsync(off_dev.ptr, off64.data(), sizeof(unsigned long long) * off64.size(), hipMemcpyHostToDevice, b->stream));
+    SBA_TRY_HIP(out_dev.alloc(2 * total * sizeof(double)));
+  }
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->depth_out_host + static_cast<size_t>(B) * sba::DEPTH_ROW);
+
+  // One launch for the whole stage: every pair's solver runs on the device next to its passes (batch_depth_solve_kernel).
+  // SBA_BATCH_DEVICE_DEPTH=0 keeps the host lock-step loop below (the A/B and the cross-check of tests/test_gpu_batch.py).
+  bool device_solve = true;
+  if (const char* env = std::getenv("SBA_BATCH_DEVICE_DEPTH")) device_solve = std::strcmp(env, "0") != 0;
+  if (device_solve) {
+    sba::BatchLmIo* io = b->lm_io_host;
+    for (int g = 0; g < B; ++g) { io[g] = sba::BatchLmIo{}; io[g].status = SBA_ERR_NUMERIC; }
+    const unsigned long long seq = ++b->depth_seq;
+    unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(b->depth_out_host_dev + static_cast<size_t>(B) * sba::DEPTH_ROW);
+    SBA_TRY_HIP(sba::launch_batch_depth_solve(b->store, pl, b->desc_dev, b->depth_const_dev, B, lambda, c, o, b->dplane[0], b->dplane[1],
+                                              w1, w2, sc1, sc2, off_dev.as<unsigned long long>(), want_out ? out_dev.as<double>() : nullptr,
+                                              b->lm_io_host_dev, b->lm_ticket, flag_dev, seq, b->stream));
+    if (want_out)
+      SBA_TRY_HIP(hipMemcpyAsync(d12_out + 2 * base, out_dev.ptr, 2 * total * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    int wrc = want_out ? sba::stream_wait(b->stream, "batched d-only stage", &b->poisoned)
+                       : sba::wait_for_sequence(flag, seq, b->stream, "batched d-only stage", &b->poisoned);
+    if (wrc) return wrc;
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    int failures = 0;
+    for (int g = 0; g < B; ++g) {
+      if (summaries) { summaries[g] = io[g].summary; summaries[g].seconds_total = seconds; }   // wall clock of the whole batch
+      if (status) status[g] = io[g].status;
+      if (io[g].status != SBA_OK) ++failures;
+    }
+    if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed in the d-only stage (see per-pair status)", failures, B);
+    return SBA_OK;
+  }
+
   std::vector<sba::DepthStageSolver> solver(B);
   std::vector<unsigned char> flip(B, 0), active(B, 1);
   for (int g = 0; g < B; ++g) solver[g].start(o);
   int remaining = B;
-  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->depth_out_host + static_cast<size_t>(B) * sba::DEPTH_ROW);
   while (remaining > 0) {
     for (int g = 0; g < B; ++g) {
       sba::BatchDepthPass& ps = b->depth_pass_host[g];
@@ -591,22 +632,11 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
     }
   }
   // results back into the batch's own depth planes (pairs that ended on an odd number of accepted steps), and out to the host
-  sba::DeviceBuffer flip_dev(&b->poisoned), off_dev(&b->poisoned), out_dev(&b->poisoned);
   SBA_TRY_HIP(flip_dev.alloc(static_cast<size_t>(B)));
   SBA_TRY_HIP(hipMemcpyAsync(flip_dev.ptr, flip.data(), static_cast<size_t>(B), hipMemcpyHostToDevice, b->stream));
-  // d12_out is indexed like the uploaded arrays (pair g at offsets[g]); the device buffer holds rows offsets[0] .. offsets[B]
-  const size_t base = b->offsets.empty() ? 0 : b->offsets.front();
-  std::vector<unsigned long long> off64;
-  for (size_t v : b->offsets) off64.push_back(v - base);
-  const size_t total = b->offsets.empty() ? 0 : b->offsets.back() - base;
-  if (d12_out && total > 0) {
-    SBA_TRY_HIP(off_dev.alloc(sizeof(unsigned long long) * off64.size()));
-    SBA_TRY_HIP(hipMemcpyAsync(off_dev.ptr, off64.data(), sizeof(unsigned long long) * off64.size(), hipMemcpyHostToDevice, b->stream));
-    SBA_TRY_HIP(out_dev.alloc(2 * total * sizeof(double)));
-  }
   SBA_TRY_HIP(sba::launch_batch_depth_finish(b->store, b->desc_dev, flip_dev.as<unsigned char>(), B, b->dplane[0], b->dplane[1], w1, w2,
-                                             off_dev.as<unsigned long long>(), d12_out && total > 0 ? out_dev.as<double>() : nullptr, b->stream));
-  if (d12_out && total > 0)
+                                             off_dev.as<unsigned long long>(), want_out ? out_dev.as<double>() : nullptr, b->stream));
+  if (want_out)
     SBA_TRY_HIP(hipMemcpyAsync(d12_out + 2 * base, out_dev.ptr, 2 * total * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   { const int _rc = sba::stream_wait(b->stream, "batched d-only stage", &b->poisoned); if (_rc) return _rc; }
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

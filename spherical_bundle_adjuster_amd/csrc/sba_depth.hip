@@ -338,6 +338,113 @@ __global__ __launch_bounds__(512, 2) void batch_depth_step_kernel(Planes pl, con
   }
 }
 
+// The whole d-only stage of a pair in ONE launch: the block that owns the pair keeps the pair's DepthStageSolver (the very
+// class the host drives -- sba_depth_solver.hpp and sba_line_search.hpp are __host__ __device__) in LDS, thread 0 feeds it the
+// nine reductions of the pass just run and takes the next request from it, the block runs that pass.  No host round trip
+// per pass and no lock-step: a pair that converges after 9 passes frees its CU slot while its neighbour runs 36.  At the
+// end the block copies the pair's depths back into the batch's own planes when they ended up in the work planes, writes
+// them out in init_d layout (out != nullptr), and thread 0 delivers summary / status through the pair's mapped host record
+// (the record of batch_lm_kernel; rot / tran / d1 / d2 are not used, pad_ carries the number of passes).
+// Loop shape as batch_lm_kernel: the thread-0 region of a trip sits between two barriers of that trip, the trip bound is
+// a counter every thread keeps, the exit decision is read from LDS after the second barrier.
+template <typename ST>
+__global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, const PairDesc* __restrict__ desc,
+                                                                  const BatchDepthConst* __restrict__ cst, double lambda, double c,
+                                                                  sba_lm_options opt, double* __restrict__ a1, double* __restrict__ a2,
+                                                                  double* __restrict__ b1, double* __restrict__ b2,
+                                                                  double* __restrict__ sc1, double* __restrict__ sc2,
+                                                                  const unsigned long long* __restrict__ offsets,
+                                                                  double* __restrict__ out, BatchLmIo* __restrict__ io,
+                                                                  unsigned int* __restrict__ ticket,
+                                                                  unsigned long long* __restrict__ seq_host, unsigned long long seq,
+                                                                  int max_trips) {
+  __shared__ double red[8][DEPTH_OUT_COUNT];
+  __shared__ double res_s[DEPTH_ROW];
+  __shared__ double req_s[2];                 // radius, alpha of the next pass
+  __shared__ int flags_s, done_s, flip_s, passes_s;
+  __shared__ alignas(16) unsigned char solver_mem[sizeof(DepthStageSolver)];
+  DepthStageSolver* solver = reinterpret_cast<DepthStageSolver*>(solver_mem);
+  const unsigned pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const PairDesc dsc = desc[pair];
+  const BatchPairMap<ST> map{dsc};
+  DepthParams P;
+  {
+    const BatchDepthConst k = cst[pair];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) P.R[i] = k.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.t[i] = k.t[i];
+  }
+  P.lambda = lambda; P.c = c; P.min_diagonal = opt.min_lm_diagonal; P.max_diagonal = opt.max_lm_diagonal;
+  P.jacobi_scaling = opt.jacobi_scaling ? 1 : 0; P.stream_stores = 0; P.n = dsc.n;
+  if (tid == 0) {
+    new (solver) DepthStageSolver();
+    solver->start(opt);
+    flip_s = 0;
+    passes_s = 0;
+  }
+  for (int trip = 0; trip < max_trips; ++trip) {
+    __syncthreads();                        // B0: the previous pass's reductions are in res_s
+    if (tid == 0) {
+      if (trip > 0) {
+        solver->feed(res_s);
+        if (solver->take_candidate()) flip_s ^= 1;
+      }
+      done_s = solver->done() ? 1 : 0;
+      if (!done_s) {
+        const DepthPassRequest& rq = solver->request();
+        req_s[0] = rq.radius; req_s[1] = rq.alpha;
+        flags_s = (rq.first ? 1 : 0) | (rq.keep_diagonal ? 2 : 0) | (flip_s ? 8 : 0);
+        ++passes_s;
+      }
+    }
+    __syncthreads();                        // B1: done_s / the next pass are visible to the block
+    if (done_s) break;
+    const int fl = flags_s;
+    P.radius = req_s[0]; P.inv_radius = 1.0 / P.radius; P.alpha = req_s[1];
+    P.first_iteration = fl & 1; P.reuse_diagonal = (fl >> 1) & 1;
+    const bool flip = (fl >> 3) & 1;
+    double r[DEPTH_OUT_COUNT];
+    depth_stream<ST, 1, BatchPairMap<ST>>(pl, flip ? b1 : a1, flip ? b2 : a2, flip ? a1 : b1, flip ? a2 : b2, sc1, sc2, P,
+                                          static_cast<size_t>(tid), 512, r, map);
+    const double s = depth_block_fold<8>(r, red);
+    if (tid < DEPTH_OUT_COUNT) res_s[tid] = s;
+  }
+  __syncthreads();                          // flip_s is final; every store of the last pass has been issued by its thread
+  {
+    const bool fl = flip_s != 0;            // as batch_depth_finish_kernel, for this block's own pair
+    const size_t npairs = (dsc.n + 1) / 2;
+    if (fl || out)
+      for (size_t pr = tid; pr < npairs; pr += 512) {
+        const size_t q = map(pr);
+        const double2 u = reinterpret_cast<const double2*>(fl ? b1 : a1)[q], v = reinterpret_cast<const double2*>(fl ? b2 : a2)[q];
+        if (fl) { reinterpret_cast<double2*>(a1)[q] = u; reinterpret_cast<double2*>(a2)[q] = v; }
+        if (out) {
+          const size_t i = offsets[pair] + 2 * pr;
+          reinterpret_cast<double2*>(out)[i] = make_double2(u.x, v.x);
+          if (2 * pr + 1 < dsc.n) reinterpret_cast<double2*>(out)[i + 1] = make_double2(u.y, v.y);
+        }
+      }
+  }
+  if (tid == 0) {
+    BatchLmIo res{};
+    res.summary = solver->summary();
+    res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // the trip bound ran out: cannot happen, but never silent
+    res.pad_ = passes_s;
+    io[pair] = res;
+    if (seq_host) {                         // completion as batch_lm_kernel: record in host memory, then a ticket
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(seq_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 // After the stage: pairs whose result sits in the work planes (flip) are copied back into the batch's depth planes, and --
 // when out != nullptr -- every pair's depths are written in init_d layout (double[total][2], pair g at offsets[g]).
 template <typename ST>
@@ -451,6 +558,28 @@ hipError_t launch_batch_depth_step(int store, const Planes& pl, const PairDesc* 
   else
     hipLaunchKernelGGL((batch_depth_step_kernel<float>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, pass_host_dev, lambda, c,
                        min_diagonal, max_diagonal, a1, a2, b1, b2, sc1, sc2, out_host_dev, ticket, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_depth_solve(int store, const Planes& pl, const PairDesc* desc, const BatchDepthConst* cst, int num_pairs,
+                                    double lambda, double c, const sba_lm_options& opt, double* a1, double* a2, double* b1, double* b2,
+                                    double* sc1, double* sc2, const unsigned long long* offsets_dev, double* out_dev, BatchLmIo* io,
+                                    unsigned int* ticket, unsigned long long* seq_host_dev, unsigned long long seq,
+                                    hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  // passes a pair can need: per iteration the trust-region pass, up to max_num_line_search_step_size_iterations
+  // contractions and one pass that restores the full step; one more pass detects the iteration limit
+  const long long its = opt.max_num_iterations > 0 ? opt.max_num_iterations : 0;
+  const long long lsn = opt.max_num_line_search_step_size_iterations > 0 ? opt.max_num_line_search_step_size_iterations : 0;
+  long long bound = its * (lsn + 2) + 4;
+  if (bound > (1ll << 24)) bound = 1ll << 24;
+  const int max_trips = static_cast<int>(bound);
+  if (store == 0)
+    hipLaunchKernelGGL((batch_depth_solve_kernel<double>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, lambda, c, opt, a1, a2,
+                       b1, b2, sc1, sc2, offsets_dev, out_dev, io, ticket, seq_host_dev, seq, max_trips);
+  else
+    hipLaunchKernelGGL((batch_depth_solve_kernel<float>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, lambda, c, opt, a1, a2,
+                       b1, b2, sc1, sc2, offsets_dev, out_dev, io, ticket, seq_host_dev, seq, max_trips);
   return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ struct DepthPassRequest {
 
 class DepthStageSolver {
  public:
-  void start(const sba_lm_options& o) {
+  SBA_HD void start(const sba_lm_options& o) {
     o_ = o;
     sum_ = sba_lm_summary{};
     sum_.termination = SBA_TERM_FAILURE;
@@ -65,13 +65,13 @@ class DepthStageSolver {
     rc_ = SBA_OK;
     make_request(1.0, false);
   }
-  bool done() const { return done_; }
-  int status() const { return rc_; }                       // SBA_OK or SBA_ERR_NUMERIC
-  const DepthPassRequest& request() const { return rq_; }
-  const sba_lm_summary& summary() const { return sum_; }
-  bool take_candidate() { const bool s = swap_; swap_ = false; return s; }
+  SBA_HD bool done() const { return done_; }
+  SBA_HD int status() const { return rc_; }                       // SBA_OK or SBA_ERR_NUMERIC
+  SBA_HD const DepthPassRequest& request() const { return rq_; }
+  SBA_HD const sba_lm_summary& summary() const { return sum_; }
+  SBA_HD bool take_candidate() { const bool s = swap_; swap_ = false; return s; }
 
-  void feed(const double* out) {
+  SBA_HD void feed(const double* out) {
     if (done_) return;
     sum_.num_evaluations++;
     first_ = false;
@@ -87,13 +87,13 @@ class DepthStageSolver {
  private:
   enum Phase { kMain, kSearch, kRestore };
 
-  void make_request(double alpha, bool keep_diagonal) {
+  SBA_HD void make_request(double alpha, bool keep_diagonal) {
     rq_.alpha = alpha;
     rq_.keep_diagonal = keep_diagonal;
     rq_.first = first_;
     rq_.radius = radius_;
   }
-  void finish(int term, int rc = SBA_OK) {
+  SBA_HD void finish(int term, int rc = SBA_OK) {
     sum_.termination = term;
     sum_.final_cost = cost_;
     sum_.final_gradient_max_norm = gmax_;
@@ -101,10 +101,11 @@ class DepthStageSolver {
     rc_ = rc;
     done_ = true;
   }
-  void next_iteration() { phase_ = kMain; make_request(1.0, reuse_); }
+  SBA_HD void next_iteration() { phase_ = kMain; make_request(1.0, reuse_); }
 
   // the alpha = 1 pass at the current depths
-  void feed_main(const double* out) {
+  SBA_HD void feed_main(const double* out) {
+    SBA_NO_CONTRACT
     cost_ = out[DEPTH_OUT_COST];
     gmax_ = out[DEPTH_OUT_GMAX];
     model_ = out[DEPTH_OUT_MODEL];
@@ -134,7 +135,8 @@ class DepthStageSolver {
     }
     decide(out);
   }
-  void after_search_trial(const double* out) {
+  SBA_HD void after_search_trial(const double* out) {
+    SBA_NO_CONTRACT
     if (!search_.done()) {                       // a contraction: same delta, smaller step
       phase_ = kSearch;
       planes_alpha_ = search_.query();
@@ -151,7 +153,8 @@ class DepthStageSolver {
     decide(out);
   }
   // `out` belongs to the final candidate of this iteration
-  void decide(const double* out) {
+  SBA_HD void decide(const double* out) {
+    SBA_NO_CONTRACT
     const double cand_cost = out[DEPTH_OUT_CAND_COST];
     if (std::sqrt(out[DEPTH_OUT_STEP2]) <= o_.parameter_tolerance * (std::sqrt(x2_) + o_.parameter_tolerance)) {
       finish(SBA_TERM_CONVERGENCE_PARAMETER);

@@ -219,6 +219,14 @@ hipError_t launch_batch_depth_step(int store, const Planes& pl, const PairDesc* 
                                    double* out_host_dev, unsigned int* ticket, unsigned long long seq, hipStream_t stream);
 // pairs with flip_dev[pair] != 0: work planes -> the batch's depth planes; out_dev != nullptr: every pair's depths in init_d
 // layout at offsets_dev[pair]
+// The whole d-only stage of every pair in one launch (batch_depth_solve_kernel: one DepthStageSolver per pair on the device).
+// io: the mapped per-pair records of the batch (summary, status; pad_ = passes run); offsets_dev / out_dev as for
+// launch_batch_depth_finish (out_dev may be null); seq_host_dev receives `seq` once every pair has delivered.
+hipError_t launch_batch_depth_solve(int store, const Planes& pl, const PairDesc* desc, const BatchDepthConst* cst, int num_pairs,
+                                    double lambda, double c, const sba_lm_options& opt, double* a1, double* a2, double* b1, double* b2,
+                                    double* sc1, double* sc2, const unsigned long long* offsets_dev, double* out_dev, BatchLmIo* io,
+                                    unsigned int* ticket, unsigned long long* seq_host_dev, unsigned long long seq,
+                                    hipStream_t stream);
 hipError_t launch_batch_depth_finish(int store, const PairDesc* desc, const unsigned char* flip_dev, int num_pairs, double* a1,
                                      double* a2, const double* b1, const double* b2, const unsigned long long* offsets_dev,
                                      double* out_dev, hipStream_t stream);

@@ -24,6 +24,25 @@
 
 #include "../../include/sba_hip.h"
 
+// The whole search is __host__ __device__: the host drives the single-problem and the lock-step batched d-only stage with
+// it, the one-launch batched stage (batch_depth_solve_kernel) runs one per pair on the device -- the same source.
+#ifndef SBA_HD
+#if defined(__HIPCC__)
+#define SBA_HD __host__ __device__
+#else
+#define SBA_HD
+#endif
+#endif
+// The step logic is the same SOURCE on both sides and is meant to give the same BITS: no fused multiply-adds on the device
+// where the host (x86-64 baseline) has none.  Block-scoped, so the per-match loops of the including kernels keep theirs.
+#ifndef SBA_NO_CONTRACT
+#if defined(__clang__)
+#define SBA_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define SBA_NO_CONTRACT
+#endif
+#endif
+
 namespace sba {
 namespace ls {
 
@@ -33,7 +52,8 @@ struct Sample { double x, f, df; };
 struct Hermite {
   int m = 0;            // number of coefficients (2 * count)
   double z[6], c[6];    // p(x) = c0 + c1 (x - z0) + c2 (x - z0)(x - z1) + ...
-  void fit(const Sample* s, int count) {
+  SBA_HD void fit(const Sample* s, int count) {
+    SBA_NO_CONTRACT
     m = 2 * count;
     double q[6][6];
     for (int k = 0; k < count; ++k) {
@@ -47,7 +67,8 @@ struct Hermite {
     for (int i = 0; i < m; ++i) c[i] = q[i][i];
   }
   // monomial coefficients a[0] + a[1] x + ... + a[m-1] x^(m-1)
-  void monomial(double* a) const {
+  SBA_HD void monomial(double* a) const {
+    SBA_NO_CONTRACT
     for (int i = 0; i < m; ++i) a[i] = 0.0;
     a[0] = c[m - 1];
     int deg = 0;
@@ -59,15 +80,20 @@ struct Hermite {
   }
 };
 
-inline double horner(const double* a, int n, double x) {   // a[0..n-1], ascending powers
+SBA_HD inline double horner(const double* a, int n, double x) {   // a[0..n-1], ascending powers
+  SBA_NO_CONTRACT
   double v = 0.0;
   for (int i = n - 1; i >= 0; --i) v = v * x + a[i];
   return v;
 }
 
 // All real roots of a[0] + ... + a[n-1] x^(n-1) inside [lo, hi] (n <= 6), by isolating them between the critical
-// points of the polynomial (found the same way one degree lower) and bisecting each monotone piece.
-inline int real_roots_in(const double* a, int n, double lo, double hi, double* roots) {
+// points of the polynomial (found the same way one degree lower) and bisecting each monotone piece.  The descent over the
+// degree is a template (NMAX = most coefficients this level can be handed), not a run-time recursion: the device build
+// needs no call stack for it.
+template <int NMAX>
+SBA_HD inline int real_roots_in(const double* a, int n, double lo, double hi, double* roots) {
+  SBA_NO_CONTRACT
   while (n > 1 && a[n - 1] == 0.0) --n;
   if (n <= 1) return 0;
   if (n == 2) {
@@ -77,8 +103,13 @@ inline int real_roots_in(const double* a, int n, double lo, double hi, double* r
   }
   double d[6], crit[6];
   for (int i = 1; i < n; ++i) d[i - 1] = i * a[i];
-  const int nc = real_roots_in(d, n - 1, lo, hi, crit);
-  std::sort(crit, crit + nc);
+  const int nc = real_roots_in<(NMAX > 2 ? NMAX - 1 : 2)>(d, n - 1, lo, hi, crit);
+  for (int i = 1; i < nc; ++i) {          // ascending (at most 4 values): insertion sort
+    const double v = crit[i];
+    int j = i - 1;
+    for (; j >= 0 && crit[j] > v; --j) crit[j + 1] = crit[j];
+    crit[j + 1] = v;
+  }
   double edge[8];
   int ne = 0;
   edge[ne++] = lo;
@@ -103,10 +134,20 @@ inline int real_roots_in(const double* a, int n, double lo, double hi, double* r
   }
   return nr;
 }
+template <>
+SBA_HD inline int real_roots_in<2>(const double* a, int n, double lo, double hi, double* roots) {
+  SBA_NO_CONTRACT
+  while (n > 1 && a[n - 1] == 0.0) --n;
+  if (n <= 1) return 0;
+  const double r = -a[0] / a[1];       // n == 2 here: a level that can be handed at most two coefficients
+  if (r >= lo && r <= hi) { roots[0] = r; return 1; }
+  return 0;
+}
 
 // argmin over [lo, hi] of the Hermite interpolant of the samples; candidates in Ceres' order (mid, lo, hi, critical
 // points), a later candidate wins only if strictly smaller.
-inline double hermite_argmin(const Sample* s, int count, double lo, double hi) {
+SBA_HD inline double hermite_argmin(const Sample* s, int count, double lo, double hi) {
+  SBA_NO_CONTRACT
   Hermite h;
   h.fit(s, count);
   double a[6], d[6], roots[6];
@@ -117,7 +158,7 @@ inline double hermite_argmin(const Sample* s, int count, double lo, double hi) {
   if (vlo < best_v) { best_v = vlo; best_x = lo; }
   if (vhi < best_v) { best_v = vhi; best_x = hi; }
   for (int i = 1; i < n; ++i) d[i - 1] = i * a[i];
-  const int nr = real_roots_in(d, n - 1, lo, hi, roots);
+  const int nr = real_roots_in<5>(d, n - 1, lo, hi, roots);      // the derivative of a quintic at most: 5 coefficients
   for (int i = 0; i < nr; ++i) {
     const double v = horner(a, n, roots[i]);
     if (v < best_v) { best_v = v; best_x = roots[i]; }
@@ -127,7 +168,8 @@ inline double hermite_argmin(const Sample* s, int count, double lo, double hi) {
 
 class ArmijoSearch {
  public:
-  void start(const sba_lm_options& o, double cost0, double gradient0, double direction_max_norm) {
+  SBA_HD void start(const sba_lm_options& o, double cost0, double gradient0, double direction_max_norm) {
+    SBA_NO_CONTRACT
     o_ = o;
     s0_ = Sample{0.0, cost0, gradient0};
     dmax_ = direction_max_norm;
@@ -136,14 +178,15 @@ class ArmijoSearch {
     done_ = success_ = false;
     query_ = 1.0;
   }
-  bool done() const { return done_; }
-  bool success() const { return success_; }
-  double query() const { return query_; }             // step size to evaluate next
-  double step_size() const { return success_ ? cur_.x : 1.0; }
-  int num_iterations() const { return iterations_; }  // contractions (what Ceres adds to num_line_search_steps)
+  SBA_HD bool done() const { return done_; }
+  SBA_HD bool success() const { return success_; }
+  SBA_HD double query() const { return query_; }             // step size to evaluate next
+  SBA_HD double step_size() const { return success_ ? cur_.x : 1.0; }
+  SBA_HD int num_iterations() const { return iterations_; }  // contractions (what Ceres adds to num_line_search_steps)
 
   // value / directional derivative (gradient at the projected trial point . delta) at query()
-  void feed(double value, double dir_gradient) {
+  SBA_HD void feed(double value, double dir_gradient) {
+    SBA_NO_CONTRACT
     if (done_) return;
     const bool valid = std::isfinite(value);
     cur_ = Sample{query_, value, dir_gradient};

@@ -115,6 +115,11 @@ hipError_t launch_batch_depth_step(int, const Planes&, const PairDesc*, const Ba
                                    unsigned long long seq, hipStream_t) {
   publish(host, static_cast<size_t>(DEPTH_ROW) * np, seq); return hipSuccess;
 }
+hipError_t launch_batch_depth_solve(int, const Planes&, const PairDesc*, const BatchDepthConst*, int, double, double, const sba_lm_options&,
+                                    double*, double*, double*, double*, double*, double*, const unsigned long long*, double*, BatchLmIo*,
+                                    unsigned int*, unsigned long long* seq_host, unsigned long long seq, hipStream_t) {
+  publish(reinterpret_cast<double*>(seq_host), 0, seq); return hipSuccess;
+}
 hipError_t launch_batch_depth_finish(int, const PairDesc*, const unsigned char*, int, double*, double*, const double*, const double*,
                                      const unsigned long long*, double*, hipStream_t) { return hipSuccess; }
 // ---- the resident kernels, emulated by a host thread that speaks the device side of the protocol (sba_resident.hpp) -------

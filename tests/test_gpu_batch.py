@@ -79,14 +79,17 @@ def test_interleaved_pair_layout_is_bit_identical_to_the_contiguous_one(sizes, s
 
 @pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
 @pytest.mark.parametrize("layout", ["0", "1"], ids=["contiguous", "interleaved"])
-def test_batch_depth_stage_matches_single_problem_stages(oracle, store, layout, monkeypatch):
+@pytest.mark.parametrize("driver", ["1", "0"], ids=["one-launch", "lock-step"])
+def test_batch_depth_stage_matches_single_problem_stages(oracle, store, layout, driver, monkeypatch):
     """sba_batch_solve_depths: the d-only stage (reference .cpp:196-197, :1004-1063) for every pair of a batch -- B
-    independent bounded problems, each with its own trust region, projected line search and convergence, advanced in
-    lock-step by one launch per pass.  Per pair it must do what sba_problem_solve_depths does for that pair alone: same
+    independent bounded problems, each with its own trust region, projected line search and convergence; driven by one
+    DepthStageSolver per pair ON THE DEVICE in one launch (batch_depth_solve_kernel), or -- SBA_BATCH_DEVICE_DEPTH=0 -- by B
+    host solvers in lock-step, one launch per pass.  Per pair it must do what sba_problem_solve_depths does for that pair alone: same
     iteration / accepted-step / contraction counts and termination, depths to 1e-9 -- ragged pairs, an empty one, a
     1-match one, pairs whose full step fails Armijo (start d = 1) next to pairs that converge at once -- and the oracle's
     numbers; the refined depths must be the ones a following per-match sweep sees."""
     monkeypatch.setenv("SBA_BATCH_INTERLEAVE", layout)
+    monkeypatch.setenv("SBA_BATCH_DEVICE_DEPTH", driver)
     sizes = [500, 0, 257, 1, 300, 64, 1023, 2] + [150 + 7 * g for g in range(40)]
     cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=6)                 # seed 6, n = 500: one contraction to a = 0.49
     B = len(sizes)
@@ -122,6 +125,30 @@ def test_batch_depth_stage_matches_single_problem_stages(oracle, store, layout, 
             assert np.abs(d[lo:hi] - dref).max() <= 1e-7 * max(1.0, np.abs(dref).max())
     assert contractions >= 1                                            # the batch really exercised the line search
     assert len({s_.num_evaluations for s_, n in zip(sums, sizes) if n > 0}) > 1      # ... and pairs finished at different passes
+
+
+def test_batch_depth_stage_one_launch_equals_lock_step_bitwise(monkeypatch):
+    """The device-resident solvers and the host lock-step solvers are the same source fed the same nine reductions: every
+    pair's depths, counts and final cost must agree to the bit (options off the defaults too: no line search, few iterations)."""
+    sizes = [3000, 1, 0, 777, 4096, 50] + [900 + 31 * g for g in range(30)]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=11)
+    rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
+    start = np.full_like(d12, 1.5)
+    for opts in (None, api.default_lm_options(max_num_line_search_step_size_iterations=0), api.default_lm_options(max_num_iterations=3)):
+        got = {}
+        for driver in ("1", "0"):
+            monkeypatch.setenv("SBA_BATCH_DEVICE_DEPTH", driver)
+            with api.Batch(0) as b:
+                b.upload(x1, x2, off, start)
+                got[driver] = b.solve_depths(rot, tran, options=opts)
+        d_dev, s_dev, st_dev = got["1"]
+        d_host, s_host, st_host = got["0"]
+        assert np.array_equal(st_dev, st_host) and (st_dev == 0).all()
+        assert np.array_equal(d_dev, d_host)
+        for a, h in zip(s_dev, s_host):
+            assert (a.num_iterations, a.num_successful_steps, a.num_line_search_steps, a.num_evaluations, a.termination, a.final_cost,
+                    a.final_radius) == (h.num_iterations, h.num_successful_steps, h.num_line_search_steps, h.num_evaluations,
+                                        h.termination, h.final_cost, h.final_radius)
 
 
 def test_batch_solve_matches_single_problem_solves(oracle):

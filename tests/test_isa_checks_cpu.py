@@ -33,12 +33,17 @@ def _makefile_flags():
     return flags
 
 
-def _compile_asm(tmp_path_factory, extra):
-    out = tmp_path_factory.mktemp("isa") / "sba_batch_kernels.s"
+def _compile_asm(tmp_path_factory, extra, source="sba_batch_kernels.hip"):
+    out = tmp_path_factory.mktemp("isa") / (os.path.splitext(source)[0] + ".s")
     hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
     subprocess.run([hipcc, *_makefile_flags(), *extra, "-S", "--cuda-device-only",
-                    os.path.join(CSRC, "sba_batch_kernels.hip"), "-o", str(out)], check=True, capture_output=True, cwd=CSRC)
+                    os.path.join(CSRC, source), "-o", str(out)], check=True, capture_output=True, cwd=CSRC)
     return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def depth_asm(tmp_path_factory):
+    return _compile_asm(tmp_path_factory, [], "sba_depth.hip")
 
 
 @pytest.fixture(scope="module")
@@ -138,3 +143,26 @@ def test_lm_kernel_scratch_is_the_solver_frame_only(batch_asm):
         sizes[m.group(1)] = int(m.group(2))
     assert sizes, "no kernel metadata found"
     assert max(sizes.values()) <= 512, sizes
+
+
+def test_depth_solve_kernels_barriers_are_block_uniform(depth_asm):
+    """batch_depth_solve_kernel (one DepthStageSolver per pair on the device) and resident_depth_kernel have the loop shape
+    of batch_lm_kernel: B0, B1 and the fold's barrier at loop depth 1 -- the solver's own loops (line-search bisection)
+    sit in the thread-0 region and hold no barrier -- and one barrier after the loop at depth 0."""
+    funcs = _functions(depth_asm)
+    for pat, count in (("batch_depth_solve_kernel", 2), ("resident_depth_kernel", 2)):
+        ks = {k: v for k, v in funcs.items() if pat in k}
+        assert len(ks) == count, (pat, sorted(ks))
+        for name, body in ks.items():
+            d = sorted(_barrier_depths(body))
+            assert d == [0, 1, 1, 1], (name, d)
+
+
+def test_depth_solve_kernel_keeps_the_stream_out_of_scratch(depth_asm):
+    """The solver (thread 0) may use a scratch frame for its polynomial work; the budget here is what was measured when the
+    kernel was written -- a jump means the per-match loop started to spill."""
+    sizes = {}
+    for m in re.finditer(r"\.name:\s+(\S*batch_depth_solve_kernel\S*)\n(?:.*\n){0,40}?\s+\.private_segment_fixed_size:\s+(\d+)", depth_asm):
+        sizes[m.group(1)] = int(m.group(2))
+    assert len(sizes) == 2, sizes
+    assert max(sizes.values()) <= 1024, sizes
