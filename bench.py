@@ -266,6 +266,36 @@ def run_c5(a):
                              "ideal_balanced_s = the same pair-passes spread evenly at the d-only kernel's own 0.72 of peak"}
         except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the line down
             depth = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        # the 8-point initial guess of every pair (reference .cpp:47-181): group moments of all pairs in one launch + trials
+        guess = None
+        try:
+            b.initial_guess(80, 0.25, 1, check=False)
+            t_g = time.perf_counter()
+            ge, gt, gnc, gst = b.initial_guess(80, 0.25, 1, check=False)       # moments, 80 trials, consensus: all on the device
+            g_dev = time.perf_counter() - t_g
+            t_g = time.perf_counter()
+            b.epipolar_moments()
+            g_mom = time.perf_counter() - t_g
+            os.environ["SBA_BATCH_DEVICE_GUESS"] = "0"
+            try:
+                t_g = time.perf_counter()
+                he, ht, hnc, hst = b.initial_guess(80, 0.25, 1, check=False)
+                g_1 = time.perf_counter() - t_g
+                api.set_host_threads(0)
+                t_g = time.perf_counter()
+                b.initial_guess(80, 0.25, 1, check=False)
+                g_auto = time.perf_counter() - t_g
+            finally:
+                api.set_host_threads(1)
+                del os.environ["SBA_BATCH_DEVICE_GUESS"]
+            guess = {"seconds": g_dev, "pairs_per_s": B / g_dev, "seconds_moments_and_copy_alone": g_mom,
+                     "seconds_host_trials_1_thread": g_1, "seconds_host_trials_auto_threads": g_auto,
+                     "pairs_with_a_candidate": int((gst == 0).sum()), "moments_algorithmic_bytes": B * n * 48,
+                     "max_abs_difference_to_host_trials": float(max(np.abs(ge - he).max(), np.abs(gt - ht).max())),
+                     "what": "sba_batch_initial_guess: 64 x 45 group moments of every pair in one launch, then 80 trials + consensus "
+                             "pick per pair in a second (one block per pair); host-trial figures: SBA_BATCH_DEVICE_GUESS=0"}
+        except Exception as e:      # noqa: BLE001
+            guess = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     remap = None
     if rank == 0 and a.frames > 0:
         # "equi2cube remap on GPU": device-resident frames, 3840x1920 -> S = 600 strip, 6 B per output pixel
@@ -323,7 +353,7 @@ def run_c5(a):
                    "max_iterations": max(s_.num_iterations for s_ in sums),
                    "all_converged": bool((status == 0).all() and all(s_.termination.startswith("CONV") for s_ in sums)),
                    "max_rot_err_rad": float(max(np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)))},
-            "depth_stage": depth,
+            "depth_stage": depth, "initial_guess": guess,
             "equi2cube": remap, "upload_s": upload_s,
         }
         if not a.no_cpu_baseline and world == 1:
@@ -536,7 +566,7 @@ def c5_leg(steps: int, warmup: int):
                 "steps": d["steps"], "warmup": d["warmup"], "step": d["config"]["step"],
                 "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch",
                                                     "sweep_kernel_alone")},
-                "lm": d["lm"], "depth_stage": d.get("depth_stage"), "equi2cube": d["equi2cube"],
+                "lm": d["lm"], "depth_stage": d.get("depth_stage"), "initial_guess": d.get("initial_guess"), "equi2cube": d["equi2cube"],
                 "what": "child run of `python bench.py --workload c5` (same K / W) after the timed region"}
     except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}

@@ -411,13 +411,26 @@ int sba_batch_step_is_fused(const sba_batch* b);
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,
                     const double* d2, const sba_lm_options* opt, sba_lm_summary* summaries, int* status);
 
+/* The 8-point initial guess (initial_guess, spherical_bundle_adjuster.cpp:47-181) of every pair of the batch -- what running
+ * the reference once per pair does first.  Device part: the 64 x 45 group moments of every pair in one launch (one block per
+ * pair; group = (match index WITHIN the pair / 2) % 64, as sba_problem_epipolar_moments on that pair alone; the sums differ
+ * from it in summation order only).  groups: double[num_pairs][64][45].                                              */
+int sba_batch_epipolar_moments(sba_batch* b, double* groups);
+/* Both parts: pair g's result is what sba_initial_guess_from_moments makes of pair g's moments with the same trials /
+ * subset_fraction / seed.  rot_euler, tran: double[num_pairs][3] (R_vec_out, T_vec_out of the reference, per pair);
+ * num_candidates (may be NULL): int[num_pairs]; status (may be NULL): int[num_pairs], SBA_OK or SBA_ERR_NUMERIC (no valid
+ * rotation candidate: that pair's outputs are zeros).  Returns SBA_ERR_NUMERIC when any pair failed.                  */
+int sba_batch_initial_guess(sba_batch* b, int trials, double subset_fraction, unsigned long long seed, double* rot_euler,
+                            double* tran, int* num_candidates, int* status);
+
 /* The d-only stage (spherical_bundle_adjuster.cpp:196-197, functor :1004-1063) for EVERY pair of the batch: what
  * sba_problem_solve_depths does for one problem, per pair -- its own trust region, projected line search and convergence;
- * the pairs advance in lock-step, one launch per pass of all unfinished pairs.  rot, tran: double[num_pairs][3] (frozen);
+ * ONE launch: the block that owns a pair runs the pair's whole stage, its solver included (SBA_BATCH_DEVICE_DEPTH=0 in the
+ * environment: host solvers in lock-step, one launch per pass -- same results to the bit).  rot, tran: double[num_pairs][3] (frozen);
  * needs per-match depths uploaded (the initial values) and refines them on the device, so that a following
  * SBA_DEPTH_PER_MATCH sweep / solve sees them; d12_out (may be NULL): double[offsets[num_pairs]][2], indexed like the uploaded d12
  * (the reference then takes d12_out[offsets[g]][0] and d12_out[offsets[g] + 1][0] as the pair's uniform depths of the rot /
- * tran stages, .cpp:941-942).  summaries / status as sba_batch_solve.  One 512-thread block per pair and pass: made for
+ * tran stages, .cpp:941-942).  summaries / status as sba_batch_solve.  One 512-thread block per pair: made for
  * batches of many pairs (config C5); a batch of a few huge pairs is served, but by as many CUs as it has pairs.      */
 int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, double lambda, double c,
                            const sba_lm_options* opt, double* d12_out, sba_lm_summary* summaries, int* status);

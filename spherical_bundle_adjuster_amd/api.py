@@ -483,6 +483,26 @@ class Batch:
         return d12, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
 
 
+    def epipolar_moments(self):
+        """Group moments of every pair: (B, 64, 45)."""
+        g = np.zeros((max(self.num_pairs, 1), 64, 45))
+        cabi.check(self._lib, self._lib.sba_batch_epipolar_moments(self._h, _dptr(g)))
+        return g[:self.num_pairs]
+
+    def initial_guess(self, trials: int = 80, subset_fraction: float = 0.25, seed: int = 0, check: bool = True):
+        """The 8-point initial guess of every pair (reference initial_guess, .cpp:47-181, once per pair).
+        Returns (rot_euler (B, 3), tran (B, 3), num_candidates (B,), status (B,)); check=False: a pair without a valid
+        candidate is reported in status only."""
+        B = self.num_pairs
+        e, t = np.zeros((max(B, 1), 3)), np.zeros((max(B, 1), 3))
+        nc, status = np.zeros(max(B, 1), dtype=np.int32), np.zeros(max(B, 1), dtype=np.int32)
+        rc = self._lib.sba_batch_initial_guess(self._h, trials, subset_fraction, seed, _dptr(e), _dptr(t),
+                                               nc.ctypes.data_as(C.POINTER(C.c_int)), status.ctypes.data_as(C.POINTER(C.c_int)))
+        if check or rc != cabi.SBA_ERR_NUMERIC:
+            cabi.check(self._lib, rc)
+        return e[:B], t[:B], nc[:B], status[:B]
+
+
 def set_host_threads(n: int) -> None:
     """Host threads for the host-side trial loop of the initial guess (reference: set_omp).  0 = auto."""
     lib = cabi.load_library()

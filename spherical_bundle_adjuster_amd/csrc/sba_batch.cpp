@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "sba_depth_solver.hpp"
+#include "sba_epipolar.hpp"
 #include "sba_internal.hpp"
 #include "sba_lm.hpp"
 #include "sba_rotation.hpp"
@@ -65,6 +66,11 @@ struct sba_batch {
   double* depth_out_host = nullptr;           // pinned + mapped: [num_pairs][16] results, then the sequence word
   double* depth_out_host_dev = nullptr;
   unsigned long long depth_seq = 0;
+  // batched initial guess (allocated on first use): the 64 x 45 group moments of every pair
+  double* epi_groups_dev = nullptr;
+  double* epi_groups_host = nullptr;          // pinned
+  sba::BatchGuessOut* guess_out_dev = nullptr;
+  sba::BatchGuessOut* guess_out_host = nullptr;   // pinned
 };
 
 namespace {
@@ -86,6 +92,11 @@ int free_batch_data(sba_batch* b) {
   if (b->depth_const_dev) SBA_TRY_HIP(hipFree(b->depth_const_dev));
   if (b->depth_pass_host) SBA_TRY_HIP(hipHostFree(b->depth_pass_host));
   if (b->depth_out_host) SBA_TRY_HIP(hipHostFree(b->depth_out_host));
+  if (b->epi_groups_dev) SBA_TRY_HIP(hipFree(b->epi_groups_dev));
+  if (b->epi_groups_host) SBA_TRY_HIP(hipHostFree(b->epi_groups_host));
+  if (b->guess_out_dev) SBA_TRY_HIP(hipFree(b->guess_out_dev));
+  if (b->guess_out_host) SBA_TRY_HIP(hipHostFree(b->guess_out_host));
+  b->epi_groups_dev = nullptr; b->epi_groups_host = nullptr; b->guess_out_dev = nullptr; b->guess_out_host = nullptr;
   b->depth_work = nullptr; b->depth_const_dev = nullptr; b->depth_pass_host = nullptr; b->depth_pass_host_dev = nullptr;
   b->depth_out_host = nullptr; b->depth_out_host_dev = nullptr; b->depth_seq = 0; b->offsets.clear(); b->plane_elems = 0;
   b->lm_io_host = nullptr; b->lm_io_host_dev = nullptr; b->lm_ticket = nullptr;
@@ -647,6 +658,103 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
     if (solver[g].status() != SBA_OK) ++failures;
   }
   if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed in the d-only stage (see per-pair status)", failures, B);
+  return SBA_OK;
+}
+
+// ---- the 8-point initial guess of every pair (reference initial_guess, .cpp:47-181, once per pair) -----------------------------
+namespace {
+// the moments of every pair -> b->epi_groups_dev; to_host: also -> b->epi_groups_host, synchronised
+int batch_group_moments(sba_batch* b, bool to_host) {
+  const int B = b->num_pairs;
+  const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
+  if (!b->epi_groups_dev) {
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->epi_groups_dev), gsz * B * sizeof(double)));
+    SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->epi_groups_host), gsz * B * sizeof(double), hipHostMallocDefault));
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->guess_out_dev), sizeof(sba::BatchGuessOut) * B));
+    SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->guess_out_host), sizeof(sba::BatchGuessOut) * B, hipHostMallocDefault));
+  }
+  sba::Planes pl;
+  for (int k = 0; k < 3; ++k) { pl.x1[k] = b->coord[k]; pl.x2[k] = b->coord[3 + k]; }
+  pl.d1 = b->dplane[0]; pl.d2 = b->dplane[1];
+  SBA_TRY_HIP(sba::launch_batch_epipolar_moments(b->store, pl, b->desc_dev, B, b->epi_groups_dev, b->stream));
+  if (!to_host) return SBA_OK;
+  SBA_TRY_HIP(hipMemcpyAsync(b->epi_groups_host, b->epi_groups_dev, gsz * B * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  return sba::stream_wait(b->stream, "batched group moments", &b->poisoned);
+}
+}  // namespace
+
+int sba_batch_epipolar_moments(sba_batch* b, double* groups) {
+  if (!b || !groups) return sba::set_error(SBA_ERR_INVALID_ARG, "null argument");
+  SBA_REFUSE_POISONED(b);
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  if (b->num_pairs == 0) return SBA_OK;
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  const int rc = batch_group_moments(b, true);
+  if (rc) return rc;
+  std::memcpy(groups, b->epi_groups_host, static_cast<size_t>(b->num_pairs) * sba::epi::kGroups * sba::epi::kMom * sizeof(double));
+  return SBA_OK;
+}
+
+int sba_batch_initial_guess(sba_batch* b, int trials, double subset_fraction, unsigned long long seed, double* rot_euler,
+                            double* tran, int* num_candidates, int* status) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  SBA_REFUSE_POISONED(b);
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  if (trials < 1 || !(subset_fraction > 0.0) || subset_fraction > 1.0)
+    return sba::set_error(SBA_ERR_INVALID_ARG, "bad trials / subset_fraction");
+  const int B = b->num_pairs;
+  if (B == 0) return SBA_OK;
+  if (!rot_euler || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "rot_euler/tran must not be null");
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  // The trials and the consensus pick run on the device too, one block per pair (batch_guess_kernel: the host's own source
+  // for a trial).  SBA_BATCH_DEVICE_GUESS=0, or more trials than the kernel holds: the host loop below.
+  bool device_trials = trials <= sba::kGuessMaxTrials;
+  if (const char* env = std::getenv("SBA_BATCH_DEVICE_GUESS")) device_trials = device_trials && std::strcmp(env, "0") != 0;
+  if (device_trials) {
+    int rc = batch_group_moments(b, false);
+    if (rc) return rc;
+    SBA_TRY_HIP(sba::launch_batch_guess(b->epi_groups_dev, B, trials, subset_fraction, seed, b->guess_out_dev, b->stream));
+    SBA_TRY_HIP(hipMemcpyAsync(b->guess_out_host, b->guess_out_dev, sizeof(sba::BatchGuessOut) * B, hipMemcpyDeviceToHost, b->stream));
+    rc = sba::stream_wait(b->stream, "batched initial guess", &b->poisoned);
+    if (rc) return rc;
+    int failures = 0;
+    for (int g = 0; g < B; ++g) {
+      const sba::BatchGuessOut& r = b->guess_out_host[g];
+      for (int i = 0; i < 3; ++i) { rot_euler[3 * g + i] = r.euler[i]; tran[3 * g + i] = r.tran[i]; }
+      if (num_candidates) num_candidates[g] = r.num_candidates;
+      if (status) status[g] = r.status;
+      if (r.status != SBA_OK) ++failures;
+    }
+    if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs have no valid rotation candidate (see per-pair status)", failures, B);
+    return SBA_OK;
+  }
+  const int rc = batch_group_moments(b, true);
+  if (rc) return rc;
+  // the trials of a pair are ~0.5 ms of small-matrix host work: pairs are spread over the host threads (sba_set_host_threads,
+  // the reference's set_omp), each pair's trials run serially in trial order -- the result does not depend on the thread count
+  const size_t gsz = static_cast<size_t>(sba::epi::kGroups) * sba::epi::kMom;
+  std::vector<int> st(B, SBA_OK);
+  auto run = [&](int first, int last) {
+    for (int g = first; g < last; ++g) {
+      const sba::epi::GuessResult r = sba::epi::initial_guess_from_groups(b->epi_groups_host + gsz * g, trials, subset_fraction, seed, 1);
+      if (num_candidates) num_candidates[g] = r.num_candidates;
+      for (int i = 0; i < 3; ++i) { rot_euler[3 * g + i] = r.picked >= 0 ? r.euler[i] : 0.0; tran[3 * g + i] = r.picked >= 0 ? r.tran[i] : 0.0; }
+      if (r.picked < 0) st[g] = SBA_ERR_NUMERIC;
+    }
+  };
+  const int nt = std::max(1, std::min(sba::host_threads(), B));
+  if (nt == 1) {
+    run(0, B);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t)
+      pool.emplace_back(run, static_cast<int>(static_cast<long long>(B) * t / nt), static_cast<int>(static_cast<long long>(B) * (t + 1) / nt));
+    run(0, static_cast<int>(static_cast<long long>(B) / nt));
+    for (auto& th : pool) th.join();
+  }
+  int failures = 0;
+  for (int g = 0; g < B; ++g) { if (status) status[g] = st[g]; if (st[g] != SBA_OK) ++failures; }
+  if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs have no valid rotation candidate (see per-pair status)", failures, B);
   return SBA_OK;
 }
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "sba_device.hpp"
+#include "sba_pair_map.hpp"
 #include "sba_resident.hpp"
 
 namespace sba {
@@ -82,19 +83,8 @@ struct DepthRegs {
 // next ones -- would two steps ahead (+40 VGPRs: 227, still two waves per SIMD) feed the memory system better?  Measured:
 // no -- 177.4 us per pass against 169.1 us (rocprofv3 averages over 54 launches, same box; profiles/r03_depth_ahead.log).
 // One step ahead is the default; SBA_DEPTH_AHEAD=2 keeps the variant reachable.
-// MAP: logical pair-of-matches index -> index into the planes (identity for a single problem; the batch's pair layout,
-// contiguous or interleaved tiles, for a pair of a batch).
-struct IdentityMap { __device__ __forceinline__ size_t operator()(size_t pr) const { return pr; } };
-template <typename ST> struct BatchPairMap;
-template <> struct BatchPairMap<double> {      // f64 planes: a 16-byte vector holds one pair of matches
-  PairDesc d;
-  __device__ __forceinline__ size_t operator()(size_t pr) const { return pair_vector(d, pr); }
-};
-template <> struct BatchPairMap<float> {       // f32 coordinate planes: a vector holds two pairs; the f64 depth planes follow it
-  PairDesc d;
-  __device__ __forceinline__ size_t operator()(size_t pr) const { return 2 * pair_vector(d, pr >> 1) + (pr & 1); }
-};
-
+// MAP: logical pair-of-matches index -> index into the planes (sba_pair_map.hpp: identity for a single problem; the batch's
+// pair layout, contiguous or interleaved tiles, for a pair of a batch).
 template <typename ST, int AHEAD, typename MAP = IdentityMap>
 __device__ __forceinline__ void depth_stream(const Planes& pl, const double* __restrict__ d1, const double* __restrict__ d2,
                                              double* __restrict__ c1, double* __restrict__ c2, double* __restrict__ sc1,

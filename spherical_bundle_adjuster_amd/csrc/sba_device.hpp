@@ -236,6 +236,18 @@ hipError_t launch_batch_depth_finish(int store, const PairDesc* desc, const unsi
 hipError_t launch_epipolar_moments(int store, const Planes& pl, size_t n, double* partials, int grid,
                                    double* groups_dev, hipStream_t stream);
 
+// The 64 x 45 group moments of every pair of a batch: groups_dev[num_pairs][64][45], one block per pair.
+hipError_t launch_batch_epipolar_moments(int store, const Planes& pl, const PairDesc* desc, int num_pairs, double* groups_dev,
+                                         hipStream_t stream);
+
+// The trials and the consensus pick of every pair on the device (batch_guess_kernel): one block per pair reads the pair's
+// group moments and writes its record.  trials <= kGuessMaxTrials.
+constexpr int kGuessMaxTrials = 128;
+struct BatchGuessOut { double euler[3]; double tran[3]; int num_candidates; int status; };
+static_assert(sizeof(BatchGuessOut) == 56, "BatchGuessOut layout");
+hipError_t launch_batch_guess(const double* groups_dev, int num_pairs, int trials, double fraction, unsigned long long seed,
+                              BatchGuessOut* out_dev, hipStream_t stream);
+
 // ... the same A^T A per TRIAL over explicit index lists (the reference's own random subsets, .cpp:130-141):
 // indices_dev [trials][m] int32, moments_dev [trials][45].
 hipError_t launch_epipolar_subset_moments(int store, const Planes& pl, size_t n, const int* indices_dev, int trials, int m,

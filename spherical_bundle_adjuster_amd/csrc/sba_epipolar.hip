@@ -15,6 +15,8 @@
 // all blocks are folded per (group, entry) by epipolar_fold_kernel in a fixed order.  Reads the same planes as the
 // sweep kernel (48 B per match), once per problem -- not on the per-iteration path.
 #include "sba_device.hpp"
+#include "sba_epipolar.hpp"
+#include "sba_pair_map.hpp"
 
 namespace sba {
 namespace {
@@ -151,6 +153,162 @@ __global__ __launch_bounds__(1024) void epipolar_fold_kernel(const double* __res
   }
 }
 
+// ---- the same group moments for every pair of a batch (sba_batch_initial_guess) ------------------------------------------------
+// One 512-thread block per pair: lane l of every wave streams the pair's vectors pr = 64 * k + l through the pair's tile map
+// (sba_pair_map.hpp), so lane id == group id exactly as above (group = (match index within the pair / 2) % 64), and the
+// eight waves combine through LDS in a fixed order (7,6 -> 5,4 -> 3,2 -> 1,0 -> 0).  groups[pair][lane][45].
+template <typename ST>
+__global__ __launch_bounds__(512) void batch_epipolar_moments_kernel(Planes pl, const PairDesc* __restrict__ desc,
+                                                                     double* __restrict__ groups) {
+  __shared__ double red[2][kSums][64];
+  double acc[kSums];
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const PairDesc dsc = desc[blockIdx.x];
+  const BatchPairMap<ST> map{dsc};
+  const size_t n = dsc.n, nvec = (n + 1) / 2;
+  constexpr size_t stride = 512;
+  size_t q = threadIdx.x;
+  double cur[6][2], nx1[6][2], nx2[6][2];
+  if (q < nvec) {
+    const size_t v = map(q);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { load2<ST>(pl.x1[k], v, cur[k]); load2<ST>(pl.x2[k], v, cur[3 + k]); }
+  }
+  if (q + stride < nvec) {
+    const size_t v = map(q + stride);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { load2<ST>(pl.x1[k], v, nx1[k]); load2<ST>(pl.x2[k], v, nx1[3 + k]); }
+  }
+  while (q < nvec) {
+    const size_t q2 = q + 2 * stride;
+    if (q2 < nvec) {
+      const size_t v = map(q2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { load2<ST>(pl.x1[k], v, nx2[k]); load2<ST>(pl.x2[k], v, nx2[3 + k]); }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (2 * q + h < n) add_match(cur[0][h], cur[1][h], cur[2][h], cur[3][h], cur[4][h], cur[5][h], acc);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { cur[k][h] = nx1[k][h]; nx1[k][h] = nx2[k][h]; }
+    q += stride;
+  }
+  // waves (2s+1, 2s) hand their sums to waves (2s-1, 2s-2) through the two LDS slots, s = 3, 2, 1; then wave 1 -> wave 0
+#pragma unroll
+  for (int top = 6; top >= 2; top -= 2) {
+    if (wave == top || wave == top + 1) {
+#pragma unroll
+      for (int k = 0; k < kSums; ++k) red[wave - top][k][lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave == top - 2 || wave == top - 1) {
+#pragma unroll
+      for (int k = 0; k < kSums; ++k) acc[k] += red[wave - (top - 2)][k][lane];
+    }
+    __syncthreads();
+  }
+  if (wave == 1) {
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) red[0][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) red[1][k][lane] = acc[k] + red[0][k][lane];    // own column only: no barrier needed
+    double* row = groups + (static_cast<size_t>(blockIdx.x) * 64 + lane) * kMom;
+    for (int e = 0; e < kMom; ++e) row[e] = red[1][kEntryMap.src[e]][lane];
+  }
+}
+
+// ---- the trials and the consensus pick of every pair of a batch, on the device ------------------------------------------------------
+// One 256-thread block per pair, fed by the pair's 64 x 45 group moments (23 KB, L2-resident right after the pass above).
+//   1. thread 0: occupancy of the groups (epi::group_occupancy);
+//   2. thread t runs trial t -- epi::group_trial, THE SOURCE the host runs (sba_epipolar.hpp is __host__ __device__, no FMA
+//      contraction): draw the groups, sum their moments in ascending group order, null vector, rank-2 projection,
+//      decomposeEssentialMat, Euler angles, validity;
+//   3. thread 0 collects the valid candidates in trial order (R1 before R2, .cpp:148-157);
+//   4. consensus pick (.cpp:162-180, epi::consensus_pick): wave w takes candidates w, w + 4, ...; its lanes compute the
+//      distances to all r candidates, rank them (stable: value, then index) so that the 20-80 % middle can be summed in ascending
+//      order -- the order the host's sort gives, hence the same bits -- lane 0 adds; thread 0 keeps the first minimum.
+// At most kGuessMaxTrials trials (the reference runs 80); more are served by the host path.
+constexpr int kGuessMaxCand = 2 * kGuessMaxTrials;
+
+__global__ __launch_bounds__(256) void batch_guess_kernel(const double* __restrict__ groups, int trials, double fraction,
+                                                          unsigned long long seed, BatchGuessOut* __restrict__ out) {
+  __shared__ epi::GroupOccupancy occ_s;
+  __shared__ epi::TrialOut trial_s[kGuessMaxTrials];
+  __shared__ float ce[kGuessMaxCand][3], ct[kGuessMaxCand][3];
+  __shared__ float sq_s[4][kGuessMaxCand];
+  __shared__ double sorted_s[4][kGuessMaxCand];
+  __shared__ double avg_s[kGuessMaxCand];
+  __shared__ int r_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* g = groups + static_cast<size_t>(blockIdx.x) * epi::kGroups * epi::kMom;
+  if (tid == 0) epi::group_occupancy(g, fraction, &occ_s);
+  __syncthreads();
+  if (tid < trials) {
+    epi::TrialOut o;
+    epi::group_trial(g, occ_s, seed, tid, &o);
+    trial_s[tid] = o;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int r = 0;
+    for (int t = 0; t < trials; ++t) {
+      const epi::TrialOut& o = trial_s[t];
+      if (o.v1) { for (int i = 0; i < 3; ++i) { ce[r][i] = o.c1.euler[i]; ct[r][i] = o.c1.tran[i]; } ++r; }
+      if (o.v2) { for (int i = 0; i < 3; ++i) { ce[r][i] = o.c2.euler[i]; ct[r][i] = o.c2.tran[i]; } ++r; }
+    }
+    r_s = r;
+  }
+  __syncthreads();
+  const int r = r_s;
+  const int lo = static_cast<int>(r * 0.2), hi = static_cast<int>(r * 0.8);
+  for (int base = 0; base < r; base += 4) {          // r comes from LDS: the trip count is block-uniform
+    const int i = base + wave;
+    if (i < r)
+      for (int j = lane; j < r; j += 64) {
+        const float dx = ce[i][0] - ce[j][0], dy = ce[i][1] - ce[j][1], dz = ce[i][2] - ce[j][2];
+        sq_s[wave][j] = dx * dx + dy * dy + dz * dz;
+      }
+    __syncthreads();
+    if (i < r)
+      for (int j = lane; j < r; j += 64) {
+        const float sj = sq_s[wave][j];
+        int rank = 0;
+        for (int k = 0; k < r; ++k) {
+          const float sk = sq_s[wave][k];
+          rank += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
+        }
+        sorted_s[wave][rank] = sqrt(static_cast<double>(sj));
+      }
+    __syncthreads();
+    if (i < r && lane == 0) {
+      double acc = 0.0;
+      for (int p = lo; p < hi; ++p) acc += sorted_s[wave][p];
+      avg_s[i] = acc / (static_cast<double>(hi - lo) * 1.0);     // 0 / 0 = NaN for r < 2, as in the reference
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    BatchGuessOut res{};
+    res.num_candidates = r;
+    res.status = r > 0 ? SBA_OK : SBA_ERR_NUMERIC;
+    if (r > 0) {
+      int best = 0;
+      double best_d = avg_s[0];
+      for (int i = 1; i < r; ++i)
+        if (avg_s[i] < best_d) { best = i; best_d = avg_s[i]; }     // std::min_element keeps the first minimum
+      for (int a = 0; a < 3; ++a) { res.euler[a] = ce[best][a]; res.tran[a] = ct[best][a]; }
+    }
+    out[blockIdx.x] = res;
+  }
+}
+
 // ---- per-trial A^T A from index lists: the reference's own subsets (initial_guess, .cpp:130-141) ---------------------------
 // Block t handles trial t: its 256 threads stride over the trial's `m` match indices (the first int(n * 0.25) entries of
 // the reference's permutation, built on the host from the process's rand() stream), gather the six coordinates of each
@@ -202,6 +360,25 @@ hipError_t launch_epipolar_subset_moments(int store, const Planes& pl, size_t n,
   else
     hipLaunchKernelGGL((epipolar_subset_moments_kernel<float>), dim3(trials), dim3(256), 0, stream, pl,
                        static_cast<unsigned long long>(n), indices_dev, m, moments_dev);
+  return hipGetLastError();
+}
+
+// groups_dev: [num_pairs][64][45] doubles.
+hipError_t launch_batch_epipolar_moments(int store, const Planes& pl, const PairDesc* desc, int num_pairs, double* groups_dev,
+                                         hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  if (store == 0)
+    hipLaunchKernelGGL((batch_epipolar_moments_kernel<double>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, groups_dev);
+  else
+    hipLaunchKernelGGL((batch_epipolar_moments_kernel<float>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, groups_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_guess(const double* groups_dev, int num_pairs, int trials, double fraction, unsigned long long seed,
+                              BatchGuessOut* out_dev, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  if (trials < 1 || trials > kGuessMaxTrials) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(batch_guess_kernel, dim3(num_pairs), dim3(256), 0, stream, groups_dev, trials, fraction, seed, out_dev);
   return hipGetLastError();
 }
 

@@ -36,6 +36,20 @@
 #include <thread>
 #include <vector>
 
+// The small-matrix work of a trial is __host__ __device__: the host runs it for a single problem and as the cross-check of
+// the batch, batch_guess_kernel (sba_epipolar.hip) runs the 80 trials of every pair of a batch on the device.  No FMA
+// contraction (as sba_rotation.hpp / sba_lm.hpp), so both compilations round alike.
+#ifndef SBA_HD
+#if defined(__HIPCC__)
+#define SBA_HD __host__ __device__
+#else
+#define SBA_HD
+#endif
+#endif
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT OFF
+#endif
+
 namespace sba {
 namespace epi {
 
@@ -44,9 +58,9 @@ constexpr int kMom = 45;        // upper triangle of the 9x9 A^T A
 
 // ---- cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 9) -------------------------------
 // On return: w ascending eigenvalues, V columns = eigenvectors (row-major n x n).
-inline void jacobi_eigen(int n, const double* A_in, double* w, double* V) {
+SBA_HD inline void jacobi_eigen(int n, const double* A_in, double* w, double* V) {
   double A[81];
-  std::memcpy(A, A_in, sizeof(double) * n * n);
+  for (int i = 0; i < n * n; ++i) A[i] = A_in[i];
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 64; ++sweep) {
@@ -81,14 +95,17 @@ inline void jacobi_eigen(int n, const double* A_in, double* w, double* V) {
       }
   }
   int order[9];
-  for (int i = 0; i < n; ++i) order[i] = i;
-  std::sort(order, order + n, [&](int a, int b) { return A[a * n + a] < A[b * n + b]; });
+  for (int i = 0; i < n; ++i) {            // ascending diagonal, insertion sort (what std::sort does below 16 elements)
+    int j = i - 1;
+    for (; j >= 0 && A[i * n + i] < A[order[j] * n + order[j]]; --j) order[j + 1] = order[j];
+    order[j + 1] = i;
+  }
   double Vs[81];
   for (int k = 0; k < n; ++k) {
     w[k] = A[order[k] * n + order[k]];
     for (int i = 0; i < n; ++i) Vs[i * n + k] = V[i * n + order[k]];
   }
-  std::memcpy(V, Vs, sizeof(double) * n * n);
+  for (int i = 0; i < n * n; ++i) V[i] = Vs[i];
 }
 
 // Eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite n x n matrix (n <= 9) -- all a trial
@@ -99,7 +116,7 @@ inline void jacobi_eigen(int n, const double* A_in, double* w, double* V) {
 //      eigenvalue lies below rho -- otherwise the iteration settled on another eigenpair.
 // Returns false whenever any step is not conclusive; the caller then runs jacobi_eigen.  The sign is fixed by
 // making the largest-magnitude component positive.
-inline bool smallest_eigvec(int n, const double* A, double* v, double* lambda) {
+SBA_HD inline bool smallest_eigvec(int n, const double* A, double* v, double* lambda) {
   double tr = 0.0;
   for (int i = 0; i < n; ++i) tr += A[i * n + i];
   if (!(tr > 0.0) || !std::isfinite(tr)) return false;
@@ -170,8 +187,8 @@ inline bool smallest_eigvec(int n, const double* A, double* v, double* lambda) {
       for (int r = c + 1; r < n; ++r)
         if (std::fabs(B[r * n + c]) > std::fabs(B[piv * n + c])) piv = r;
       if (piv != c) {
-        for (int k = 0; k < n; ++k) std::swap(B[c * n + k], B[piv * n + k]);
-        std::swap(b[c], b[piv]);
+        for (int k = 0; k < n; ++k) { const double tmp = B[c * n + k]; B[c * n + k] = B[piv * n + k]; B[piv * n + k] = tmp; }
+        const double tmp = b[c]; b[c] = b[piv]; b[piv] = tmp;
       }
       if (std::fabs(B[c * n + c]) < 1e-300 + 1e-18 * tr) B[c * n + c] = 1e-18 * tr + 1e-300;
       for (int r = c + 1; r < n; ++r) {
@@ -204,16 +221,16 @@ inline bool smallest_eigvec(int n, const double* A, double* v, double* lambda) {
   return true;
 }
 
-inline double det3(const double* M) {
+SBA_HD inline double det3(const double* M) {
   return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
-inline void mul3(const double* A, const double* B, double* C) {
+SBA_HD inline void mul3(const double* A, const double* B, double* C) {
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
 // SVD of a 3x3 matrix: E = U diag(w) Vt, w descending, U and Vt orthogonal (row-major).
-inline void svd3(const double* E, double* U, double* w, double* Vt) {
+SBA_HD inline void svd3(const double* E, double* U, double* w, double* Vt) {
   double EtE[9], lam[3], V[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) EtE[3 * i + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
@@ -255,11 +272,11 @@ inline void svd3(const double* E, double* U, double* w, double* Vt) {
 
 // cv::decomposeEssentialMat (OpenCV calib3d, call site .cpp:85): SVD, flip U / Vt to det +1,
 // R1 = U W Vt, R2 = U W^T Vt, t = last column of U.
-inline void decompose_essential(const double* E, double* R1, double* R2, double* t) {
+SBA_HD inline void decompose_essential(const double* E, double* R1, double* R2, double* t) {
   double U[9], w[3], Vt[9];
   svd3(E, U, w, Vt);
-  if (det3(U) < 0) for (double& v : U) v = -v;
-  if (det3(Vt) < 0) for (double& v : Vt) v = -v;
+  if (det3(U) < 0) for (int i = 0; i < 9; ++i) U[i] = -U[i];
+  if (det3(Vt) < 0) for (int i = 0; i < 9; ++i) Vt[i] = -Vt[i];
   const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
   double T[9];
   mul3(U, W, T); mul3(T, Vt, R1);
@@ -268,7 +285,7 @@ inline void decompose_essential(const double* E, double* R1, double* R2, double*
 }
 
 // rot2euler (.cpp:25-45): single-precision like the reference (float sy, float x/y/z, Vec3f).
-inline void rot_to_euler(const double* R, float out[3]) {
+SBA_HD inline void rot_to_euler(const double* R, float out[3]) {
   const float sy = static_cast<float>(std::sqrt(R[0] * R[0] + R[3] * R[3]));
   if (!(sy < 1e-6f)) {
     out[0] = static_cast<float>(std::atan2(R[7], R[8]));
@@ -282,7 +299,7 @@ inline void rot_to_euler(const double* R, float out[3]) {
 }
 
 // max_vec (.cpp:14-22), including its behaviour on ties.
-inline double max_vec(const float v[3]) {
+SBA_HD inline double max_vec(const float v[3]) {
   if (v[0] > v[1] && v[0] > v[2]) return v[0];
   if (v[1] > v[2]) return v[1];
   return v[2];
@@ -295,7 +312,7 @@ struct Candidate {
   int which;   // 1 = R1, 2 = R2
 };
 
-inline uint64_t splitmix64(uint64_t& s) {
+SBA_HD inline uint64_t splitmix64(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -304,13 +321,13 @@ inline uint64_t splitmix64(uint64_t& s) {
 
 // The groups trial `trial` draws: the first `count` entries of a Fisher-Yates shuffle, seeded by (seed, trial), of the
 // `n_items` candidate groups in `items` (nullptr: 0..n_items-1).  A longer draw extends a shorter one.
-inline void trial_groups(uint64_t seed, int trial, int count, int* out, const int* items = nullptr, int n_items = kGroups) {
+SBA_HD inline void trial_groups(uint64_t seed, int trial, int count, int* out, const int* items = nullptr, int n_items = kGroups) {
   uint64_t s = seed * 0x2545F4914F6CDD1Dull + static_cast<uint64_t>(trial) * 0xD6E8FEB86659FD93ull + 1;
   int perm[kGroups];
   for (int i = 0; i < n_items; ++i) perm[i] = items ? items[i] : i;
   for (int i = 0; i < count && i < n_items; ++i) {
     const int j = i + static_cast<int>(splitmix64(s) % static_cast<uint64_t>(n_items - i));
-    std::swap(perm[i], perm[j]);
+    const int tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp;
     out[i] = perm[i];
   }
 }
@@ -320,7 +337,7 @@ inline void trial_groups(uint64_t seed, int trial, int count, int* out, const in
 // row of vt from cv::SVDecomp of the rows x 9 matrix A (.cpp:70-73), and with fewer than 9 rows vt has only `rows` rows --
 // its last one is the singular vector of the SMALLEST OF THE `rows` singular values, not a null vector of A; in terms of
 // A^T A: the eigenvector of the rows-th largest eigenvalue.
-inline void trial_from_moments(const double* mom45, float e1[3], float e2[3], float tv[3], bool* v1, bool* v2,
+SBA_HD inline void trial_from_moments(const double* mom45, float e1[3], float e2[3], float tv[3], bool* v1, bool* v2,
                                double* E_out /* 9, may be null */, int rows = 0) {
   double S[81], w[9], V[81];
   int k = 0;
@@ -339,7 +356,7 @@ inline void trial_from_moments(const double* mom45, float e1[3], float e2[3], fl
   svd3(E, U, sv, Vt);
   const double D[9] = {sv[0], 0, 0, 0, sv[1], 0, 0, 0, 0};
   mul3(U, D, T); mul3(T, Vt, Ec);
-  if (E_out) std::memcpy(E_out, Ec, sizeof(Ec));
+  if (E_out) for (int i = 0; i < 9; ++i) E_out[i] = Ec[i];
   double R1[9], R2[9], t[3];
   decompose_essential(Ec, R1, R2, t);
   rot_to_euler(R1, e1);
@@ -384,54 +401,68 @@ struct GuessResult {
   std::vector<Candidate> candidates;
 };
 
-// groups: [64][45] moments (the match count of a group is the trace of its matrix).  trials / fraction / seed: 80, 0.25
-// in the reference.
+// Occupancy of the groups: a row of A is kron(left, right) of two unit vectors, so it has unit length and the trace of
+// a group's A^T A IS its number of matches.  With fewer than 256 matches some of the 64 groups are empty, and a blind
+// draw of 16 groups could sum fewer than the 8 correspondences the linear system needs (the reference always takes
+// floor(n / 4) individual matches, .cpp:132-141): draw among the NON-EMPTY groups -- a quarter of them, like the
+// reference's quarter of the matches -- and keep drawing until the subset holds at least 8 matches (or every group).
+// From 256 matches on every group is occupied and holds at least 4: exactly 16 groups.
+struct GroupOccupancy {
+  int nonempty[kGroups], count[kGroups], ne, take;
+};
+SBA_HD inline void group_occupancy(const double* groups, double fraction, GroupOccupancy* o) {
+  int diag = 0;
+  int diag_index[9];
+  for (int a = 0; a < 9; ++a) { diag_index[a] = diag; diag += 9 - a; }
+  o->ne = 0;
+  for (int g = 0; g < kGroups; ++g) {
+    double tr = 0;
+    for (int a = 0; a < 9; ++a) tr += groups[g * kMom + diag_index[a]];
+    o->count[g] = std::isfinite(tr) && tr > 0.5 ? static_cast<int>(std::floor(tr + 0.5)) : 0;
+    if (o->count[g] > 0) o->nonempty[o->ne++] = g;
+  }
+  o->take = std::max(1, std::min(o->ne, static_cast<int>(o->ne * fraction)));
+}
+
+// Trial `trial` of a problem given by its group moments: draw the groups, sum their moments in ascending group order, solve.
+struct TrialOut { Candidate c1, c2; bool v1, v2; };
+SBA_HD inline void group_trial(const double* groups, const GroupOccupancy& occ, uint64_t seed, int trial, TrialOut* out) {
+  TrialOut& o = *out;
+  o.c1 = Candidate{}; o.c2 = Candidate{}; o.v1 = o.v2 = false;
+  if (occ.ne == 0) return;
+  int sel[kGroups];
+  trial_groups(seed, trial, occ.ne, sel, occ.nonempty, occ.ne);
+  int used = occ.take, matches = 0;
+  for (int s = 0; s < used; ++s) matches += occ.count[sel[s]];
+  while (matches < 8 && used < occ.ne) matches += occ.count[sel[used++]];
+  for (int i = 1; i < used; ++i) {                  // ascending: fixed summation order
+    const int v = sel[i];
+    int j = i - 1;
+    for (; j >= 0 && sel[j] > v; --j) sel[j + 1] = sel[j];
+    sel[j + 1] = v;
+  }
+  double mom[kMom];
+  for (int k = 0; k < kMom; ++k) mom[k] = 0.0;
+  for (int s = 0; s < used; ++s)
+    for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
+  float tv[3];
+  trial_from_moments(mom, o.c1.euler, o.c2.euler, tv, &o.v1, &o.v2, nullptr);
+  for (int i = 0; i < 3; ++i) o.c1.tran[i] = o.c2.tran[i] = tv[i];
+  o.c1.trial = o.c2.trial = trial; o.c1.which = 1; o.c2.which = 2;
+}
+
+// groups: [64][45] moments.  trials / fraction / seed: 80, 0.25 in the reference.
 // Trials are independent (the subset of trial k depends on (seed, k) only), so they run on `threads` host threads --
 // what the reference's set_omp(num_proc) does for its loops -- and are collected in trial order: the result does not
 // depend on the thread count.
 inline GuessResult initial_guess_from_groups(const double* groups, int trials, double fraction, uint64_t seed,
                                              int threads = 1) {
   GuessResult res;
-  // Occupancy of the groups: a row of A is kron(left, right) of two unit vectors, so it has unit length and the trace of
-  // a group's A^T A IS its number of matches.  With fewer than 256 matches some of the 64 groups are empty, and a blind
-  // draw of 16 groups could sum fewer than the 8 correspondences the linear system needs (the reference always takes
-  // floor(n / 4) individual matches, .cpp:132-141): draw among the NON-EMPTY groups -- a quarter of them, like the
-  // reference's quarter of the matches -- and keep drawing until the subset holds at least 8 matches (or every group).
-  // From 256 matches on every group is occupied and holds at least 4: exactly 16 groups, as before.
-  int nonempty[kGroups], count[kGroups], ne = 0;
-  {
-    int diag = 0;
-    int diag_index[9];
-    for (int a = 0; a < 9; ++a) { diag_index[a] = diag; diag += 9 - a; }
-    for (int g = 0; g < kGroups; ++g) {
-      double tr = 0;
-      for (int a = 0; a < 9; ++a) tr += groups[g * kMom + diag_index[a]];
-      count[g] = std::isfinite(tr) && tr > 0.5 ? static_cast<int>(std::lround(tr)) : 0;
-      if (count[g] > 0) nonempty[ne++] = g;
-    }
-  }
-  const int take = std::max(1, std::min(ne, static_cast<int>(ne * fraction)));
-  struct TrialOut { Candidate c1, c2; bool v1, v2; };
+  GroupOccupancy occ;
+  group_occupancy(groups, fraction, &occ);
   std::vector<TrialOut> out(static_cast<size_t>(std::max(trials, 0)));
   auto run = [&](int first, int last) {
-    for (int trial = first; trial < last; ++trial) {
-      TrialOut& o = out[trial];
-      o.c1 = Candidate{}; o.c2 = Candidate{}; o.v1 = o.v2 = false;
-      if (ne == 0) continue;
-      int sel[kGroups];
-      trial_groups(seed, trial, ne, sel, nonempty, ne);
-      int used = take, matches = 0;
-      for (int s = 0; s < used; ++s) matches += count[sel[s]];
-      while (matches < 8 && used < ne) matches += count[sel[used++]];
-      std::sort(sel, sel + used);                     // fixed summation order
-      double mom[kMom] = {0};
-      for (int s = 0; s < used; ++s)
-        for (int k = 0; k < kMom; ++k) mom[k] += groups[sel[s] * kMom + k];
-      float tv[3];
-      trial_from_moments(mom, o.c1.euler, o.c2.euler, tv, &o.v1, &o.v2, nullptr);
-      for (int i = 0; i < 3; ++i) o.c1.tran[i] = o.c2.tran[i] = tv[i];
-      o.c1.trial = o.c2.trial = trial; o.c1.which = 1; o.c2.which = 2;
-    }
+    for (int trial = first; trial < last; ++trial) group_trial(groups, occ, seed, trial, &out[trial]);
   };
   // A trial is ~6 us and starting a thread costs tens of us: threads only pay with hundreds of trials each, so the
   // reference's 80 trials always run serially.

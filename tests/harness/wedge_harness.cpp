@@ -110,6 +110,8 @@ hipError_t launch_depth_step(int, const Planes&, const double*, const double*, d
   publish(host, 24, seq); return hipSuccess;
 }
 hipError_t launch_epipolar_moments(int, const Planes&, size_t, double*, int, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_epipolar_moments(int, const Planes&, const PairDesc*, int, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_guess(const double*, int, int, double, unsigned long long, BatchGuessOut*, hipStream_t) { return hipSuccess; }
 hipError_t launch_batch_depth_step(int, const Planes&, const PairDesc*, const BatchDepthConst*, const BatchDepthPass*, int np, double, double,
                                    double, double, double*, double*, double*, double*, double*, double*, double* host, unsigned int*,
                                    unsigned long long seq, hipStream_t) {

@@ -151,6 +151,62 @@ def test_batch_depth_stage_one_launch_equals_lock_step_bitwise(monkeypatch):
                                         h.termination, h.final_cost, h.final_radius)
 
 
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("layout", ["0", "1"], ids=["contiguous", "interleaved"])
+def test_batch_initial_guess_matches_single_problem_guesses(store, layout, monkeypatch):
+    """sba_batch_initial_guess: the 8-point initial guess (reference .cpp:47-181) once per pair.  A pair's 64 x 45 group
+    moments equal numpy's on that pair's (stored) coordinates -- the group of a match is counted WITHIN its pair -- and
+    the single-problem pass on the pair alone up to summation order; repeated launches are bit-identical; the guess of
+    pair g is exactly what the host part makes of pair g's moments, and agrees with the single-problem guess; ragged
+    pairs, an empty pair (no candidate: status says so, the others are served), pairs below 256 matches (empty groups)."""
+    from test_initial_guess_cpu import group_moments
+    monkeypatch.setenv("SBA_BATCH_INTERLEAVE", layout)
+    sizes = [5000, 0, 257, 40, 3001, 64, 1023, 9] + [700 + 13 * g for g in range(24)]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=41)
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, d12, store=store)
+        gm = b.epipolar_moments()
+        assert np.array_equal(gm, b.epipolar_moments())
+        e_dev, t_dev, nc_dev, status_dev = b.initial_guess(80, 0.25, 7, check=False)     # trials + consensus on the device
+        assert all(np.array_equal(x, y) for x, y in zip((e_dev, t_dev, nc_dev, status_dev), b.initial_guess(80, 0.25, 7, check=False)))
+        monkeypatch.setenv("SBA_BATCH_DEVICE_GUESS", "0")
+        e, t, nc, status = b.initial_guess(80, 0.25, 7, check=False)                     # ... and on the host
+        api.set_host_threads(4)
+        try:
+            e4, t4, nc4, status4 = b.initial_guess(80, 0.25, 7, check=False)     # pairs spread over host threads: same result
+        finally:
+            api.set_host_threads(1)
+        e200 = b.initial_guess(200, 0.25, 7, check=False)                        # more trials than the kernel holds: host path
+        monkeypatch.delenv("SBA_BATCH_DEVICE_GUESS")
+        assert all(np.array_equal(x, y) for x, y in zip(e200, b.initial_guess(200, 0.25, 7, check=False)))
+        with pytest.raises(api.SbaError):
+            b.initial_guess(80, 0.25, 7)                                        # the empty pair makes the checked call fail
+    assert np.array_equal(e, e4) and np.array_equal(t, t4) and np.array_equal(nc, nc4) and np.array_equal(status, status4)
+    # device trials = the host's source, compiled for the device: same candidates, same pick.  The one libm call of a trial
+    # (double atan2, rounded to float) may differ between the two libraries in the last float bit.
+    assert np.array_equal(status_dev, status) and np.array_equal(nc_dev, nc)
+    assert np.abs(e_dev - e).max() <= 2.5e-7 and np.abs(t_dev - t).max() <= 1.2e-7
+    assert (np.abs(e_dev - e).max(axis=1) == 0).mean() >= 0.9
+    for g, c in enumerate(cs):
+        n = sizes[g]
+        if n == 0:
+            assert status[g] == cabi.SBA_ERR_NUMERIC and nc[g] == 0 and not gm[g].any()
+            continue
+        a1, a2 = ((c.x1, c.x2) if store == api.STORE_F64 else
+                  (c.x1.astype(np.float32).astype(np.float64), c.x2.astype(np.float32).astype(np.float64)))
+        ref, _, _ = group_moments(a1, a2)
+        assert np.abs(gm[g] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), (g, n)
+        eh, th, nh = api.initial_guess_from_moments(gm[g], 80, 0.25, 7)
+        assert status[g] == 0 and nc[g] == nh and np.array_equal(e[g], eh) and np.array_equal(t[g], th), (g, n)
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, c.d12, store=store)
+            gs = p.epipolar_moments()
+            es, ts, ns = p.initial_guess(80, 0.25, 7)
+        assert np.abs(gm[g] - gs).max() <= 1e-12 * max(np.abs(gs).max(), 1.0), (g, n)
+        if n >= 256:      # well-conditioned pairs: a 1e-13 difference in the moments does not move the consensus pick
+            assert ns == nc[g] and np.abs(es - e[g]).max() <= 1e-5 and np.abs(ts - t[g]).max() <= 1e-5, (g, n)
+
+
 def test_batch_solve_matches_single_problem_solves(oracle):
     sizes = [4000, 0, 2500, 3333, 1, 5000]
     cs, off, x1, x2, d12 = _make_pairs(sizes)
