@@ -296,6 +296,54 @@ def run_c5(a):
                              "pick per pair in a second (one block per pair); host-trial figures: SBA_BATCH_DEVICE_GUESS=0"}
         except Exception as e:      # noqa: BLE001
             guess = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        # the reference's whole per-pair pipeline for every pair (initial guess -> d-only -> rot-only -> tran-only), and the
+        # oracle's pipeline for a few of the same pairs on the host cores
+        pipeline = None
+        try:
+            d0 = np.full((B * n, 2), 6.0)
+            b.upload(x1, x2, off, d0)
+            b.solve_problem(seed=1, check=False)
+            times = []
+            for _ in range(3):
+                b.upload(x1, x2, off, d0)
+                t_p = time.perf_counter()
+                res = b.solve_problem(seed=1, check=False)
+                times.append(time.perf_counter() - t_p)
+            p_s = float(np.median(times))
+            counts = lambda g: (res["depth_stage"][g].num_iterations, res["depth_stage"][g].num_line_search_steps,   # noqa: E731
+                                res["rot_stage"][g].num_iterations, res["tran_stage"][g].num_iterations)
+            pipeline = {"seconds": p_s, "pairs_per_s": B / p_s, "pairs_ok": int((res["status"] == 0).sum()),
+                        "what": "sba_batch_solve_problem: 8-point consensus guess, d-only, rot-only, tran-only for all pairs "
+                                "(start d = 6); depths already resident, median of 3"}
+            if rank == 0:       # three pairs, well under a second: also in the child run of the default line
+                from oracle import oracle_py as orc
+                sample = [0, B // 2, B - 1][:max(1, min(3, B))]
+                cores = max(1, min(orc.num_procs(), usable_cores()))
+                e_g, t_g2, _, _ = b.initial_guess(80, 0.25, 1, check=False)
+
+                def cpu_pairs(threads):
+                    ts, ok, diff = [], True, 0.0
+                    for g in sample:
+                        c = cs[g]
+                        t_c = time.perf_counter()
+                        rot_s, tran_s = -e_g[g], t_g2[g]            # the oracle has no group-sampled guess of its own: stages only
+                        dd, sdd, _ = orc.depth_solve(c.x1, c.x2, rot_s, tran_s, d0[:n])
+                        r1, t1, s1, _ = orc.lm_solve(0, c.x1, c.x2, rot_s, tran_s, dd[0, 0], dd[1, 0], threads=threads)
+                        r2, t2, s2, _ = orc.lm_solve(1, c.x1, c.x2, r1, t1, dd[0, 0], dd[1, 0], threads=threads)
+                        ts.append(time.perf_counter() - t_c)
+                        ok = ok and (sdd.num_iterations, sdd.num_line_search_steps, s1.num_iterations, s2.num_iterations) == counts(g)
+                        diff = max(diff, float(np.abs(res["rot"][g] - r2).max()))
+                    return ts, ok, diff
+                runs = {th: cpu_pairs(th) for th in sorted({1, cores})}     # more threads than granted cores only add wake-ups
+                cores = min(runs, key=lambda k: np.mean(runs[k][0]))
+                cpu_t, agree, rot_diff = runs[cores]
+                per_pair = float(np.mean(cpu_t))
+                pipeline["cpu_oracle"] = {"seconds_per_pair": per_pair, "pairs_per_s": 1.0 / per_pair, "pairs_sampled": sample,
+                                          "cores": cores, "iteration_counts_equal": bool(agree), "max_abs_rot_diff": rot_diff,
+                                          "what": "oracle/sba_oracle.cpp: the three solve stages of the same pairs from the same "
+                                                  "start values (the 8-point guess is not part of this figure)"}
+        except Exception as e:      # noqa: BLE001
+            pipeline = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     remap = None
     if rank == 0 and a.frames > 0:
         # "equi2cube remap on GPU": device-resident frames, 3840x1920 -> S = 600 strip, 6 B per output pixel
@@ -353,7 +401,7 @@ def run_c5(a):
                    "max_iterations": max(s_.num_iterations for s_ in sums),
                    "all_converged": bool((status == 0).all() and all(s_.termination.startswith("CONV") for s_ in sums)),
                    "max_rot_err_rad": float(max(np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)))},
-            "depth_stage": depth, "initial_guess": guess,
+            "depth_stage": depth, "initial_guess": guess, "pipeline": pipeline,
             "equi2cube": remap, "upload_s": upload_s,
         }
         if not a.no_cpu_baseline and world == 1:
@@ -566,7 +614,7 @@ def c5_leg(steps: int, warmup: int):
                 "steps": d["steps"], "warmup": d["warmup"], "step": d["config"]["step"],
                 "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch",
                                                     "sweep_kernel_alone")},
-                "lm": d["lm"], "depth_stage": d.get("depth_stage"), "initial_guess": d.get("initial_guess"), "equi2cube": d["equi2cube"],
+                "lm": d["lm"], "depth_stage": d.get("depth_stage"), "initial_guess": d.get("initial_guess"), "pipeline": d.get("pipeline"), "equi2cube": d["equi2cube"],
                 "what": "child run of `python bench.py --workload c5` (same K / W) after the timed region"}
     except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the headline line down
         return {"ok": False, "error": f"{type(e).__name__}: {e}"}

@@ -423,6 +423,22 @@ int sba_batch_epipolar_moments(sba_batch* b, double* groups);
 int sba_batch_initial_guess(sba_batch* b, int trials, double subset_fraction, unsigned long long seed, double* rot_euler,
                             double* tran, int* num_candidates, int* status);
 
+/* The reference's whole per-pair pipeline -- do_bundle_adjustment's initial values and solve_problem
+ * (spherical_bundle_adjuster.cpp:302-331, :183-217) -- for EVERY pair of the batch: what running main/main.cpp once per ERP
+ * pair computes after matching.  use_initial_guess != 0: the 8-point consensus guess (trials, subset_fraction, seed as
+ * sba_batch_initial_guess), init_rot = -R_vec_out, init_tran = T_vec_out (.cpp:330-331); a pair without a valid candidate
+ * keeps the caller's rot / tran and is reported in status.  use_initial_guess == 0: rot / tran are the start values (the
+ * alternative the reference keeps in a comment, .cpp:328-329).  Then the d-only stage on the uploaded depths (lambda = c = 1,
+ * .cpp:1057-1058), the rot-only and the tran-only stage with init_d[0][0], init_d[1][0] of the pair as the depths of every
+ * match (.cpp:941-942, :998-999).  rot, tran: double[num_pairs][3], in (start values) / out (result).  All of the following
+ * may be NULL: d12_out (refined depths, as sba_batch_solve_depths), d_uniform double[num_pairs][2] (the two depths the
+ * last stages used), guess_candidates int[num_pairs], the three summary arrays [num_pairs], status int[num_pairs] (first
+ * failing stage's code per pair).  Returns SBA_ERR_NUMERIC when any pair failed; the other pairs' results are valid.   */
+int sba_batch_solve_problem(sba_batch* b, int use_initial_guess, int trials, double subset_fraction, unsigned long long seed,
+                            double* rot, double* tran, const sba_lm_options* opt, double* d12_out, double* d_uniform,
+                            int* guess_candidates, sba_lm_summary* depth_summaries, sba_lm_summary* rot_summaries,
+                            sba_lm_summary* tran_summaries, int* status);
+
 /* The d-only stage (spherical_bundle_adjuster.cpp:196-197, functor :1004-1063) for EVERY pair of the batch: what
  * sba_problem_solve_depths does for one problem, per pair -- its own trust region, projected line search and convergence;
  * ONE launch: the block that owns a pair runs the pair's whole stage, its solver included (SBA_BATCH_DEVICE_DEPTH=0 in the

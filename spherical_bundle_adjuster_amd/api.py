@@ -483,6 +483,30 @@ class Batch:
         return d12, [_summary(sums[i]) for i in range(self.num_pairs)], status[:self.num_pairs]
 
 
+    def solve_problem(self, rot=None, tran=None, use_initial_guess: bool = True, trials: int = 80, subset_fraction: float = 0.25,
+                      seed: int = 0, options: cabi.LmOptions | None = None, want_depths: bool = False, check: bool = True):
+        """The reference's per-pair pipeline for every pair (initial guess -> d-only -> rot-only -> tran-only,
+        reference .cpp:302-331, :183-217).  rot / tran: start values (B, 3) (needed when use_initial_guess is False; with the
+        guess they only serve pairs that have no valid candidate).  Returns a dict: rot, tran (B, 3), d_uniform (B, 2),
+        guess_candidates (B,), depth / rot / tran stage summaries, status (B,), d12 (if want_depths)."""
+        B = self.num_pairs
+        r = np.zeros((max(B, 1), 3)) if rot is None else _f64(rot).reshape(B, 3).copy()
+        t = np.zeros((max(B, 1), 3)) if tran is None else _f64(tran).reshape(B, 3).copy()
+        opt = options if options is not None else default_lm_options()
+        d12 = np.zeros((int(self._total), 2)) if want_depths else None
+        du = np.zeros((max(B, 1), 2))
+        nc, status = np.zeros(max(B, 1), dtype=np.int32), np.zeros(max(B, 1), dtype=np.int32)
+        sums = [(cabi.LmSummary * max(B, 1))() for _ in range(3)]
+        rc = self._lib.sba_batch_solve_problem(self._h, 1 if use_initial_guess else 0, trials, subset_fraction, seed, _dptr(r), _dptr(t),
+                                               C.byref(opt), d12.ctypes.data_as(C.c_void_p) if want_depths else None, _dptr(du),
+                                               nc.ctypes.data_as(C.POINTER(C.c_int)), sums[0], sums[1], sums[2],
+                                               status.ctypes.data_as(C.POINTER(C.c_int)))
+        if check or rc != cabi.SBA_ERR_NUMERIC:
+            cabi.check(self._lib, rc)
+        return {"rot": r[:B], "tran": t[:B], "d_uniform": du[:B], "guess_candidates": nc[:B], "status": status[:B], "d12": d12,
+                "depth_stage": [_summary(sums[0][i]) for i in range(B)], "rot_stage": [_summary(sums[1][i]) for i in range(B)],
+                "tran_stage": [_summary(sums[2][i]) for i in range(B)]}
+
     def epipolar_moments(self):
         """Group moments of every pair: (B, 64, 45)."""
         g = np.zeros((max(self.num_pairs, 1), 64, 45))

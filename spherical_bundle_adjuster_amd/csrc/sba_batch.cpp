@@ -531,8 +531,23 @@ int sba_batch_step_is_fused(const sba_batch* b) {
 // bounded trust-region problems -- own radius, own projected line search, own convergence -- advanced in LOCK-STEP: one
 // launch of batch_depth_step_kernel runs the next pass of every unfinished pair, the host feeds every pair's nine
 // reductions to that pair's DepthStageSolver (the very state machine of sba_problem_solve_depths).
+namespace {
+// d_uniform (may be null): double[num_pairs][2] <- the refined init_d[0][0], init_d[1][0] of every pair (the uniform depths of
+// the reference's rot / tran stages, .cpp:941-942); a pair with one match gets its only depth twice, an empty pair zeros.
+int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran, double lambda, double c, const sba_lm_options* opt,
+                            double* d12_out, sba_lm_summary* summaries, int* status, double* d_uniform);
+}  // namespace
+
 int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, double lambda, double c,
                            const sba_lm_options* opt, double* d12_out, sba_lm_summary* summaries, int* status) {
+  return batch_solve_depths_impl(b, rot, tran, lambda, c, opt, d12_out, summaries, status, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran, double lambda, double c, const sba_lm_options* opt,
+                            double* d12_out, sba_lm_summary* summaries, int* status, double* d_uniform) {
   if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
   SBA_REFUSE_POISONED(b);
   if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
@@ -581,6 +596,10 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
   for (size_t v : b->offsets) off64.push_back(v - base);
   const size_t total = b->offsets.empty() ? 0 : b->offsets.back() - base;
   sba::DeviceBuffer flip_dev(&b->poisoned), off_dev(&b->poisoned), out_dev(&b->poisoned);
+  std::vector<double> d12_tmp;                  // the lock-step path takes the uniform depths from the full read-back
+  bool device_solve = true;
+  if (const char* env = std::getenv("SBA_BATCH_DEVICE_DEPTH")) device_solve = std::strcmp(env, "0") != 0;
+  if (!device_solve && d_uniform && !d12_out && total > 0) { d12_tmp.resize(2 * (base + total)); d12_out = d12_tmp.data(); }
   const bool want_out = d12_out && total > 0;
   if (want_out) {
     SBA_TRY_HIP(off_dev.alloc(sizeof(unsigned long long) * off64.size()));
@@ -591,8 +610,6 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
 
   // One launch for the whole stage: every pair's solver runs on the device next to its passes (batch_depth_solve_kernel).
   // SBA_BATCH_DEVICE_DEPTH=0 keeps the host lock-step loop below (the A/B and the cross-check of tests/test_gpu_batch.py).
-  bool device_solve = true;
-  if (const char* env = std::getenv("SBA_BATCH_DEVICE_DEPTH")) device_solve = std::strcmp(env, "0") != 0;
   if (device_solve) {
     sba::BatchLmIo* io = b->lm_io_host;
     for (int g = 0; g < B; ++g) { io[g] = sba::BatchLmIo{}; io[g].status = SBA_ERR_NUMERIC; }
@@ -611,6 +628,7 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
     for (int g = 0; g < B; ++g) {
       if (summaries) { summaries[g] = io[g].summary; summaries[g].seconds_total = seconds; }   // wall clock of the whole batch
       if (status) status[g] = io[g].status;
+      if (d_uniform) { d_uniform[2 * g] = io[g].d1; d_uniform[2 * g + 1] = io[g].d2; }
       if (io[g].status != SBA_OK) ++failures;
     }
     if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed in the d-only stage (see per-pair status)", failures, B);
@@ -655,11 +673,19 @@ int sba_batch_solve_depths(sba_batch* b, const double* rot, const double* tran, 
   for (int g = 0; g < B; ++g) {
     if (summaries) { summaries[g] = solver[g].summary(); summaries[g].seconds_total = seconds; }   // wall clock of the whole batch
     if (status) status[g] = solver[g].status();
+    if (d_uniform) {
+      const size_t lo = b->offsets[g], n_g = b->n[g];
+      d_uniform[2 * g] = n_g > 0 ? d12_out[2 * lo] : 0.0;
+      d_uniform[2 * g + 1] = n_g > 1 ? d12_out[2 * (lo + 1)] : d_uniform[2 * g];
+    }
     if (solver[g].status() != SBA_OK) ++failures;
   }
   if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed in the d-only stage (see per-pair status)", failures, B);
   return SBA_OK;
 }
+}  // namespace
+
+extern "C" {
 
 // ---- the 8-point initial guess of every pair (reference initial_guess, .cpp:47-181, once per pair) -----------------------------
 namespace {
@@ -755,6 +781,59 @@ int sba_batch_initial_guess(sba_batch* b, int trials, double subset_fraction, un
   int failures = 0;
   for (int g = 0; g < B; ++g) { if (status) status[g] = st[g]; if (st[g] != SBA_OK) ++failures; }
   if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs have no valid rotation candidate (see per-pair status)", failures, B);
+  return SBA_OK;
+}
+
+// The reference's whole per-pair pipeline for every pair of the batch (do_bundle_adjustment -> initial_guess -> solve_problem,
+// spherical_bundle_adjuster.cpp:302-331, :183-217): 8-point consensus guess, init_rot = -R_vec_out, init_tran = T_vec_out,
+// d-only stage, rot-only and tran-only stages with the first two refined depths as the depths of every match.  Four
+// launches for the whole batch (moments, trials + consensus, d-only stage, and one per-pair LM launch per remaining stage),
+// no per-pair host work beyond copying records.
+int sba_batch_solve_problem(sba_batch* b, int use_initial_guess, int trials, double subset_fraction, unsigned long long seed,
+                            double* rot, double* tran, const sba_lm_options* opt, double* d12_out, double* d_uniform,
+                            int* guess_candidates, sba_lm_summary* depth_summaries, sba_lm_summary* rot_summaries,
+                            sba_lm_summary* tran_summaries, int* status) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  SBA_REFUSE_POISONED(b);
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  const int B = b->num_pairs;
+  if (B == 0) return SBA_OK;
+  if (!rot || !tran) return sba::set_error(SBA_ERR_INVALID_ARG, "rot/tran must not be null");
+  if (!b->has_d12) return sba::set_error(SBA_ERR_INVALID_ARG, "the pipeline needs per-match depths uploaded (init_d)");
+  std::vector<int> st(B, SBA_OK), stage_st(B, SBA_OK);
+  auto merge = [&](int rc) -> int {       // per-pair failures are collected; anything else ends the call
+    if (rc != SBA_OK && rc != SBA_ERR_NUMERIC) return rc;
+    for (int g = 0; g < B; ++g) if (st[g] == SBA_OK && stage_st[g] != SBA_OK) st[g] = stage_st[g];
+    return SBA_OK;
+  };
+  if (use_initial_guess) {
+    std::vector<double> euler(3 * B), tvec(3 * B);
+    std::fill(stage_st.begin(), stage_st.end(), SBA_OK);
+    const int rc = merge(sba_batch_initial_guess(b, trials, subset_fraction, seed, euler.data(), tvec.data(), guess_candidates, stage_st.data()));
+    if (rc) return rc;
+    for (int g = 0; g < B; ++g) {
+      if (stage_st[g] != SBA_OK) continue;           // no candidate: the pair keeps the caller's start values
+      for (int a = 0; a < 3; ++a) { rot[3 * g + a] = -euler[3 * g + a]; tran[3 * g + a] = tvec[3 * g + a]; }   // .cpp:330-331
+    }
+  } else if (guess_candidates) {
+    std::fill(guess_candidates, guess_candidates + B, 0);
+  }
+  std::vector<double> du(2 * B);
+  std::fill(stage_st.begin(), stage_st.end(), SBA_OK);
+  int rc = merge(batch_solve_depths_impl(b, rot, tran, 1.0, 1.0, opt, d12_out, depth_summaries, stage_st.data(), du.data()));   // .cpp:196-197, :1057-1058
+  if (rc) return rc;
+  std::vector<double> d1(B), d2(B);
+  for (int g = 0; g < B; ++g) { d1[g] = du[2 * g]; d2[g] = du[2 * g + 1]; }
+  if (d_uniform) std::memcpy(d_uniform, du.data(), sizeof(double) * 2 * B);
+  std::fill(stage_st.begin(), stage_st.end(), SBA_OK);
+  rc = merge(sba_batch_solve(b, SBA_MODE_ROT, SBA_DEPTH_UNIFORM, rot, tran, d1.data(), d2.data(), opt, rot_summaries, stage_st.data()));    // .cpp:202-203
+  if (rc) return rc;
+  std::fill(stage_st.begin(), stage_st.end(), SBA_OK);
+  rc = merge(sba_batch_solve(b, SBA_MODE_TRAN, SBA_DEPTH_UNIFORM, rot, tran, d1.data(), d2.data(), opt, tran_summaries, stage_st.data()));  // .cpp:208-209
+  if (rc) return rc;
+  int failures = 0;
+  for (int g = 0; g < B; ++g) { if (status) status[g] = st[g]; if (st[g] != SBA_OK) ++failures; }
+  if (failures) return sba::set_error(SBA_ERR_NUMERIC, "%d of %d pairs failed in a stage of the pipeline (see per-pair status)", failures, B);
   return SBA_OK;
 }
 

@@ -334,7 +334,8 @@ __global__ __launch_bounds__(512, 2) void batch_depth_step_kernel(Planes pl, con
 // per pass and no lock-step: a pair that converges after 9 passes frees its CU slot while its neighbour runs 36.  At the
 // end the block copies the pair's depths back into the batch's own planes when they ended up in the work planes, writes
 // them out in init_d layout (out != nullptr), and thread 0 delivers summary / status through the pair's mapped host record
-// (the record of batch_lm_kernel; rot / tran / d1 / d2 are not used, pad_ carries the number of passes).
+// (the record of batch_lm_kernel; rot / tran are not used, d1 / d2 carry the refined depths of the pair's first two matches in
+// image 1, pad_ the number of passes).
 // Loop shape as batch_lm_kernel: the thread-0 region of a trip sits between two barriers of that trip, the trip bound is
 // a counter every thread keeps, the exit decision is read from LDS after the second barrier.
 template <typename ST>
@@ -422,6 +423,12 @@ __global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, co
     res.summary = solver->summary();
     res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // the trip bound ran out: cannot happen, but never silent
     res.pad_ = passes_s;
+    // init_d[0][0] and init_d[1][0] of the pair: what the reference's rot / tran stages use as the depths of EVERY match
+    // (.cpp:941-942, :998-999).  Thread 0 stored both itself (its lane handles the pair's first two matches).
+    if (dsc.n > 0) {
+      const double2 u0 = reinterpret_cast<const double2*>(flip_s ? b1 : a1)[map(0)];
+      res.d1 = u0.x; res.d2 = dsc.n > 1 ? u0.y : u0.x;
+    }
     io[pair] = res;
     if (seq_host) {                         // completion as batch_lm_kernel: record in host memory, then a ticket
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

@@ -207,6 +207,57 @@ def test_batch_initial_guess_matches_single_problem_guesses(store, layout, monke
             assert ns == nc[g] and np.abs(es - e[g]).max() <= 1e-5 and np.abs(ts - t[g]).max() <= 1e-5, (g, n)
 
 
+@pytest.mark.parametrize("driver", ["device", "host"])
+def test_batch_pipeline_matches_single_problem_pipelines(oracle, driver, monkeypatch):
+    """sba_batch_solve_problem: the reference's per-pair pipeline (do_bundle_adjustment's initial values + solve_problem,
+    .cpp:302-331, :183-217) for every pair of a batch.  Per pair it must be the chain of the single-problem entry points
+    the mirror class runs -- guess, init_rot = -R_vec_out, d-only, rot-only and tran-only with the first two refined
+    depths -- started from the pair's own guess: same iteration counts per stage, results to 1e-9; the oracle's stages
+    give the same numbers on sampled pairs.  `host`: the predecessors of the one-launch stages (host trials, lock-step
+    d-only solvers) give the same pipeline."""
+    if driver == "host":
+        monkeypatch.setenv("SBA_BATCH_DEVICE_GUESS", "0")
+        monkeypatch.setenv("SBA_BATCH_DEVICE_DEPTH", "0")
+    sizes = [3000, 2048, 999, 4097, 1500] + [1200 + 50 * g for g in range(27)]
+    cs = [synthetic.full_rt(n, seed=5200 + i, sigma=2e-4, outlier_fraction=0.02) for i, n in enumerate(sizes)]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    x1 = np.concatenate([c.x1 for c in cs]); x2 = np.concatenate([c.x2 for c in cs])
+    B = len(sizes)
+    d0 = np.full((int(off[-1]), 2), 6.0)                                  # expected_d of the reference's command line
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, d0)
+        e, t, nc, st = b.initial_guess(80, 0.25, 5)
+        res = b.solve_problem(seed=5, want_depths=True)
+        b.upload(x1, x2, off, d0)
+        res2 = b.solve_problem(rot=-e, tran=t, use_initial_guess=False)    # the same pipeline from explicit start values
+    assert (res["status"] == 0).all() and np.array_equal(res["guess_candidates"], nc)
+    assert np.array_equal(res["rot"], res2["rot"]) and np.array_equal(res["tran"], res2["tran"])
+    assert np.array_equal(res["d_uniform"][:, 0], res["d12"][off[:-1].astype(int), 0])
+    assert np.array_equal(res["d_uniform"][:, 1], res["d12"][off[:-1].astype(int) + 1, 0])
+    for g, c in enumerate(cs):
+        lo, hi = int(off[g]), int(off[g + 1])
+        rot0, tran0 = -e[g], t[g]
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, d0[lo:hi])
+            d, sd = p.solve_depths(rot0, tran0)
+            r1, t1, s1 = p.solve(api.MODE_ROT, rot0, tran0, d[0, 0], d[1, 0])
+            r2, t2, s2 = p.solve(api.MODE_TRAN, r1, t1, d[0, 0], d[1, 0])
+        got = (res["depth_stage"][g].num_iterations, res["depth_stage"][g].num_line_search_steps, res["rot_stage"][g].num_iterations,
+               res["tran_stage"][g].num_iterations)
+        assert got == (sd.num_iterations, sd.num_line_search_steps, s1.num_iterations, s2.num_iterations), (g, got)
+        assert np.abs(res["d12"][lo:hi] - d).max() <= 1e-9 * max(1.0, np.abs(d).max())
+        assert np.abs(res["rot"][g] - r2).max() <= 1e-9 and np.abs(res["tran"][g] - t2).max() <= 1e-9, g
+        # sanity only: the reference's last two stages give every match the depths of the pair's first two (.cpp:941-942), so
+        # the pipeline's accuracy is the reference's (a few 0.01 rad on this data), not the per-match sweep's
+        assert np.abs(res["rot"][g] - c.rot_true).max() < 0.15
+        if g in (0, 3):
+            dd, sdd, _ = oracle.depth_solve(c.x1, c.x2, rot0, tran0, d0[lo:hi])
+            ro, to, so, _ = oracle.lm_solve(api.MODE_ROT, c.x1, c.x2, rot0, tran0, dd[0, 0], dd[1, 0])
+            ro2, to2, so2, _ = oracle.lm_solve(api.MODE_TRAN, c.x1, c.x2, ro, to, dd[0, 0], dd[1, 0])
+            assert (sdd.num_iterations, so.num_iterations, so2.num_iterations) == (got[0], got[2], got[3])
+            assert np.abs(res["rot"][g] - ro2).max() <= 1e-7 and np.abs(res["tran"][g] - to2).max() <= 1e-7
+
+
 def test_batch_solve_matches_single_problem_solves(oracle):
     sizes = [4000, 0, 2500, 3333, 1, 5000]
     cs, off, x1, x2, d12 = _make_pairs(sizes)
