@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void batch_epipolar_moments_kernel(Planes pl, 
 
 // ---- the trials and the consensus pick of every pair of a batch, on the device ------------------------------------------------------
 // One 256-thread block per pair, fed by the pair's 64 x 45 group moments (23 KB, L2-resident right after the pass above).
-//   1. thread 0: occupancy of the groups (epi::group_occupancy);
+//   1. the moments are staged in LDS; thread 0: occupancy of the groups (epi::group_occupancy);
 //   2. thread t runs trial t -- epi::group_trial, THE SOURCE the host runs (sba_epipolar.hpp is __host__ __device__, no FMA
 //      contraction): draw the groups, sum their moments in ascending group order, null vector, rank-2 projection,
 //      decomposeEssentialMat, Euler angles, validity;
@@ -239,23 +239,41 @@ constexpr int kGuessMaxCand = 2 * kGuessMaxTrials;
 
 __global__ __launch_bounds__(256) void batch_guess_kernel(const double* __restrict__ groups, int trials, double fraction,
                                                           unsigned long long seed, BatchGuessOut* __restrict__ out) {
+  __shared__ double g_s[epi::kGroups * epi::kMom];          // the pair's moments: every trial sums 16 of the 64 rows
   __shared__ epi::GroupOccupancy occ_s;
-  __shared__ epi::TrialOut trial_s[kGuessMaxTrials];
+  // the trial records are dead once their candidates are collected; the consensus' sorted distances reuse the space
+  constexpr size_t kSortedBytes = sizeof(double) * 2 * 4 * kGuessMaxCand;
+  static_assert(sizeof(epi::TrialOut) * kGuessMaxTrials <= kSortedBytes, "trial records must fit the buffer they share");
+  __shared__ alignas(16) unsigned char shared_buf[kSortedBytes];
+  epi::TrialOut* trial_s = reinterpret_cast<epi::TrialOut*>(shared_buf);
+  double (*sorted_s)[4][kGuessMaxCand] = reinterpret_cast<double (*)[4][kGuessMaxCand]>(shared_buf);
   __shared__ float ce[kGuessMaxCand][3], ct[kGuessMaxCand][3];
-  __shared__ float sq_s[4][kGuessMaxCand];
-  __shared__ double sorted_s[4][kGuessMaxCand];
+  __shared__ alignas(16) unsigned long long key_s[4][kGuessMaxCand];     // (bits of the squared distance) << 32 | index
   __shared__ double avg_s[kGuessMaxCand];
   __shared__ int r_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const double* g = groups + static_cast<size_t>(blockIdx.x) * epi::kGroups * epi::kMom;
-  if (tid == 0) epi::group_occupancy(g, fraction, &occ_s);
+#ifdef SBA_GUESS_PROFILE
+  long long tk[6];
+#define SBA_GTICK(i) tk[i] = wall_clock64()
+#else
+#define SBA_GTICK(i) do { } while (0)
+#endif
+  SBA_GTICK(0);
+  {
+    const double* g = groups + static_cast<size_t>(blockIdx.x) * epi::kGroups * epi::kMom;
+    for (int k = tid; k < epi::kGroups * epi::kMom; k += 256) g_s[k] = g[k];
+  }
   __syncthreads();
+  if (tid == 0) epi::group_occupancy(g_s, fraction, &occ_s);
+  __syncthreads();
+  SBA_GTICK(1);
   if (tid < trials) {
     epi::TrialOut o;
-    epi::group_trial(g, occ_s, seed, tid, &o);
+    epi::group_trial(g_s, occ_s, seed, tid, &o);
     trial_s[tid] = o;
   }
   __syncthreads();
+  SBA_GTICK(2);
   if (tid == 0) {
     int r = 0;
     for (int t = 0; t < trials; ++t) {
@@ -266,34 +284,61 @@ __global__ __launch_bounds__(256) void batch_guess_kernel(const double* __restri
     r_s = r;
   }
   __syncthreads();
+  SBA_GTICK(3);
+  // Consensus.  Group gi = candidates 4 gi + wave, one per wave.  Per trip of the loop (all trip counts come from LDS:
+  // block-uniform): A(gi) the wave's lanes write, for its candidate, the squared distance to every candidate j as the key
+  // (float bits << 32 | j) -- non-negative floats order like their bit patterns, so key order IS the stable order (value,
+  // then index) -- padded to an even count with all-ones; lane 0 adds up the sorted middle of group gi - 1 (C); barrier;
+  // B(gi) every lane ranks its up to four keys against all of them (one 64-bit compare per pair, 16-byte LDS reads shared by
+  // the four) and scatters the square roots into sorted order; barrier.  sorted_s is double-buffered by the parity of gi,
+  // so C(gi - 1) and B(gi) never meet.
   const int r = r_s;
   const int lo = static_cast<int>(r * 0.2), hi = static_cast<int>(r * 0.8);
-  for (int base = 0; base < r; base += 4) {          // r comes from LDS: the trip count is block-uniform
-    const int i = base + wave;
-    if (i < r)
-      for (int j = lane; j < r; j += 64) {
-        const float dx = ce[i][0] - ce[j][0], dy = ce[i][1] - ce[j][1], dz = ce[i][2] - ce[j][2];
-        sq_s[wave][j] = dx * dx + dy * dy + dz * dz;
-      }
-    __syncthreads();
-    if (i < r)
-      for (int j = lane; j < r; j += 64) {
-        const float sj = sq_s[wave][j];
-        int rank = 0;
-        for (int k = 0; k < r; ++k) {
-          const float sk = sq_s[wave][k];
-          rank += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
+  const int r2 = (r + 1) & ~1, ngroups = (r + 3) / 4, nu = (r + 63) / 64;
+  for (int gi = 0; gi <= ngroups; ++gi) {
+    const int i = 4 * gi + wave;
+    if (gi < ngroups && i < r)
+      for (int j = lane; j < r2; j += 64) {
+        unsigned long long key = ~0ull;
+        if (j < r) {
+          const float dx = ce[i][0] - ce[j][0], dy = ce[i][1] - ce[j][1], dz = ce[i][2] - ce[j][2];
+          key = (static_cast<unsigned long long>(__float_as_uint(dx * dx + dy * dy + dz * dz)) << 32) | static_cast<unsigned>(j);
         }
-        sorted_s[wave][rank] = sqrt(static_cast<double>(sj));
+        key_s[wave][j] = key;
       }
-    __syncthreads();
-    if (i < r && lane == 0) {
+    if (gi > 0 && lane == 0 && i - 4 < r) {
+      const double* sv = sorted_s[(gi - 1) & 1][wave];
       double acc = 0.0;
-      for (int p = lo; p < hi; ++p) acc += sorted_s[wave][p];
-      avg_s[i] = acc / (static_cast<double>(hi - lo) * 1.0);     // 0 / 0 = NaN for r < 2, as in the reference
+      int p = lo;
+      for (; p + 8 <= hi; p += 8) {          // eight loads in flight, then the adds in ascending order
+        const double v0 = sv[p], v1 = sv[p + 1], v2 = sv[p + 2], v3 = sv[p + 3], v4 = sv[p + 4], v5 = sv[p + 5], v6 = sv[p + 6], v7 = sv[p + 7];
+        acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+      }
+      for (; p < hi; ++p) acc += sv[p];
+      avg_s[i - 4] = acc / (static_cast<double>(hi - lo) * 1.0);     // 0 / 0 = NaN for r < 2, as in the reference
     }
+    __syncthreads();
+    if (gi < ngroups && i < r) {
+      unsigned long long kj[4] = {0, 0, 0, 0};
+      int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kj[u] = (u < nu && lane + 64 * u < r) ? key_s[wave][lane + 64 * u] : 0ull;
+      const ulonglong2* row = reinterpret_cast<const ulonglong2*>(key_s[wave]);
+#pragma unroll 4
+      for (int k2 = 0; k2 < r2 / 2; ++k2) {      // several 16-byte reads in flight per trip
+        const ulonglong2 v = row[k2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < nu) rank[u] += (v.x < kj[u] ? 1 : 0) + (v.y < kj[u] ? 1 : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < nu && lane + 64 * u < r)
+          sorted_s[gi & 1][wave][rank[u]] = sqrt(static_cast<double>(__uint_as_float(static_cast<unsigned>(kj[u] >> 32))));
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  SBA_GTICK(4);
   if (tid == 0) {
     BatchGuessOut res{};
     res.num_candidates = r;
@@ -305,6 +350,13 @@ __global__ __launch_bounds__(256) void batch_guess_kernel(const double* __restri
         if (avg_s[i] < best_d) { best = i; best_d = avg_s[i]; }     // std::min_element keeps the first minimum
       for (int a = 0; a < 3; ++a) { res.euler[a] = ce[best][a]; res.tran[a] = ct[best][a]; }
     }
+#ifdef SBA_GUESS_PROFILE
+    // ticks of the 100 MHz wall clock: staging + occupancy, trials, collection, consensus, pick
+    SBA_GTICK(5);
+    res.euler[0] = static_cast<double>(tk[1] - tk[0]); res.euler[1] = static_cast<double>(tk[2] - tk[1]);
+    res.euler[2] = static_cast<double>(tk[3] - tk[2]); res.tran[0] = static_cast<double>(tk[4] - tk[3]);
+    res.tran[1] = static_cast<double>(tk[5] - tk[4]);
+#endif
     out[blockIdx.x] = res;
   }
 }
