@@ -208,6 +208,12 @@ def run_c5(a):
         t_up = time.perf_counter()
         b.upload(x1, x2, off, d12)
         upload_s = time.perf_counter() - t_up
+        t_up = time.perf_counter()
+        b.upload(x1, x2, off, d12)                  # same pairs again: every allocation is reused, only the data moves
+        reupload_s = time.perf_counter() - t_up
+        t_up = time.perf_counter()
+        b.set_depths(d12)
+        set_depths_s = time.perf_counter() - t_up
         barrier()
         precond = {"sweeps": 0, "ms": 0.0}
         if a.precondition_ms > 0:
@@ -402,7 +408,8 @@ def run_c5(a):
                    "all_converged": bool((status == 0).all() and all(s_.termination.startswith("CONV") for s_ in sums)),
                    "max_rot_err_rad": float(max(np.abs(rot[g] - cs[g].rot_true).max() for g in range(B)))},
             "depth_stage": depth, "initial_guess": guess, "pipeline": pipeline,
-            "equi2cube": remap, "upload_s": upload_s,
+            "equi2cube": remap, "upload_s": upload_s, "reupload_s": reupload_s, "set_depths_s": set_depths_s,
+            "upload_bytes": int(B * n * 64),
         }
         if not a.no_cpu_baseline and world == 1:
             from oracle import oracle_py as orc

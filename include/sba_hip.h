@@ -383,6 +383,10 @@ int sba_batch_destroy(sba_batch* b);
 int sba_batch_set_kernel(sba_batch* b, int kind);
 int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_xyz, const double* d12,
                      const size_t* offsets, int num_pairs, int store);
+/* Re-send only the per-match depths (same layout as the d12 of sba_batch_upload, which must have carried depths): the
+ * counterpart of sba_problem_set_depths -- sba_batch_solve_depths / sba_batch_solve_problem refine the depths in place, the
+ * coordinates stay resident.  (sba_batch_upload with unchanged offsets / store keeps every allocation too and only moves data.) */
+int sba_batch_set_depths(sba_batch* b, const double* d12);
 int sba_batch_size(const sba_batch* b, int* num_pairs, int* blocks_per_pair);
 /* rot, tran: double[num_pairs][3]; d1, d2: double[num_pairs] uniform depths per pair (NULL = 1.0; ignored with
  * SBA_DEPTH_PER_MATCH); packs: double[num_pairs][SBA_PACK_SIZE].                                          */

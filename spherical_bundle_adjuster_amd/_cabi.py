@@ -152,6 +152,7 @@ SIGNATURES = {
     "sba_batch_solve_problem": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp, C.POINTER(LmOptions), _vp, _dp,
                                           C.POINTER(C.c_int), C.POINTER(LmSummary), C.POINTER(LmSummary), C.POINTER(LmSummary),
                                           C.POINTER(C.c_int)]),
+    "sba_batch_set_depths": (C.c_int, [_vp, _dp]),
     "sba_batch_epipolar_moments": (C.c_int, [_vp, _dp]),
     "sba_batch_initial_guess": (C.c_int, [_vp, C.c_int, C.c_double, C.c_ulonglong, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sba_keypoints_to_sphere": (C.c_int, [C.c_int, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),

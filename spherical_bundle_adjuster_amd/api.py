@@ -342,6 +342,7 @@ class Batch:
         self._h = C.c_void_p()
         cabi.check(self._lib, self._lib.sba_batch_create(C.byref(self._h), device, C.c_void_p(stream or 0)))
         self.num_pairs = 0
+        self._total = 0
 
     def close(self) -> None:
         """As Problem.close(): `destroy_status` != 0 = the batch was poisoned and its device resources were leaked."""
@@ -385,6 +386,13 @@ class Batch:
         cabi.check(self._lib, self._lib.sba_batch_upload(
             self._h, x1.ctypes.data_as(C.c_void_p), x2.ctypes.data_as(C.c_void_p), dp,
             off.ctypes.data_as(C.POINTER(C.c_size_t)), self.num_pairs, store))
+
+    def set_depths(self, d12) -> None:
+        """Re-send only the per-match depths (total, 2), laid out like the d12 of upload(); the coordinates stay resident."""
+        d = _f64(d12).reshape(-1, 2)
+        if self.num_pairs and d.shape[0] != self._total:
+            raise ValueError("d12 length differs from the uploaded pairs")
+        cabi.check(self._lib, self._lib.sba_batch_set_depths(self._h, _dptr(d)))
 
     @property
     def blocks_per_pair(self) -> int:

@@ -71,6 +71,10 @@ struct sba_batch {
   double* epi_groups_host = nullptr;          // pinned
   sba::BatchGuessOut* guess_out_dev = nullptr;
   sba::BatchGuessOut* guess_out_host = nullptr;   // pinned
+  // upload: row offsets on the device (relative to the first row), two pinned staging buffers, their DMA-done events
+  unsigned long long* offsets_dev = nullptr;
+  void* upload_pinned[2] = {nullptr, nullptr};
+  hipEvent_t upload_ev[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -94,6 +98,8 @@ int free_batch_data(sba_batch* b) {
   if (b->depth_out_host) SBA_TRY_HIP(hipHostFree(b->depth_out_host));
   if (b->epi_groups_dev) SBA_TRY_HIP(hipFree(b->epi_groups_dev));
   if (b->epi_groups_host) SBA_TRY_HIP(hipHostFree(b->epi_groups_host));
+  if (b->offsets_dev) SBA_TRY_HIP(hipFree(b->offsets_dev));
+  b->offsets_dev = nullptr;
   if (b->guess_out_dev) SBA_TRY_HIP(hipFree(b->guess_out_dev));
   if (b->guess_out_host) SBA_TRY_HIP(hipHostFree(b->guess_out_host));
   b->epi_groups_dev = nullptr; b->epi_groups_host = nullptr; b->guess_out_dev = nullptr; b->guess_out_host = nullptr;
@@ -224,6 +230,57 @@ class PairWorkers {
   std::atomic<bool> quit_{false};
 };
 
+// Host arrays -> planes.  The caller's arrays are pageable (std::vector<cv::Point3d>::data() of many image pairs, or numpy):
+// as for a large single problem (sba_shim.cpp: upload_common) a few host threads copy chunk k + 1 into one of two pinned
+// staging buffers while the DMA engine moves chunk k and ONE re-layout launch (batch_aos_to_planes_kernel: every row finds
+// its pair by bisection) turns chunk k - 1 into planes.  Chunks are 16 MiB of the CONCATENATED arrays, whatever the pair
+// boundaries.  which: bit 0 left, bit 1 right, bit 2 d12.
+constexpr size_t kBatchUploadChunk = 699050;       // rows per chunk: 16 MiB of xyz
+int batch_transfer(sba_batch* b, const double* left_xyz, const double* right_xyz, const double* d12, unsigned which) {
+  const int B = b->num_pairs;
+  const size_t base = b->offsets.front(), total = b->offsets.back() - base;
+  if (total == 0) return SBA_OK;
+  const size_t ppt = static_cast<size_t>(sba::points_per_lane(b->store));
+  const size_t chunk = std::min(kBatchUploadChunk, total), chunk_bytes = chunk * 3 * sizeof(double);
+  for (int k = 0; k < 2; ++k) {
+    if (!b->upload_pinned[k]) SBA_TRY_HIP(hipHostMalloc(&b->upload_pinned[k], kBatchUploadChunk * 3 * sizeof(double), hipHostMallocDefault));
+    if (!b->upload_ev[k]) SBA_TRY_HIP(hipEventCreateWithFlags(&b->upload_ev[k], hipEventDisableTiming));
+  }
+  sba::DeviceBuffer stage_buf(&b->poisoned);
+  SBA_TRY_HIP(stage_buf.alloc(2 * chunk_bytes));
+  char* dev_stage[2] = {stage_buf.as<char>(), stage_buf.as<char>() + chunk_bytes};
+  int threads = 6;
+  if (const char* env = std::getenv("SBA_UPLOAD_THREADS")) { const int v = std::atoi(env); if (v >= 1 && v <= 64) threads = v; }
+  threads = std::max(1, std::min<int>(threads, static_cast<int>(std::thread::hardware_concurrency())));
+  if (total * 24 < (size_t(8) << 20)) threads = 1;            // a few MB: starting threads costs more than they save
+  sba::CopyPool pool(threads);
+  struct Job { const double* src; int width; int which; };
+  const Job jobs[3] = {{left_xyz, 3, 0}, {right_xyz, 3, 1}, {d12, 2, 2}};
+  size_t k = 0;
+  for (const Job& job : jobs) {
+    if (!job.src || !(which & (1u << job.which))) continue;
+    for (size_t first = 0; first < total; first += chunk, ++k) {
+      const size_t m = std::min(chunk, total - first), bytes = m * job.width * sizeof(double);
+      const int s = static_cast<int>(k & 1);
+      if (k >= 2) {                                          // the DMA out of pinned buffer s has finished
+        const int rc = sba::event_wait(b->upload_ev[s], "batch upload staging", &b->poisoned);
+        if (rc) return rc;
+      }
+      pool.copy(b->upload_pinned[s], job.src + job.width * (base + first), bytes);
+      SBA_TRY_HIP(hipMemcpyAsync(dev_stage[s], b->upload_pinned[s], bytes, hipMemcpyHostToDevice, b->stream));
+      SBA_TRY_HIP(hipEventRecord(b->upload_ev[s], b->stream));
+      double* stage = reinterpret_cast<double*>(dev_stage[s]);      // stream order protects the device staging buffer
+      if (job.which < 2)
+        SBA_TRY_HIP(sba::launch_batch_aos_to_planes(stage, m, first, b->offsets_dev, B, b->desc_dev, ppt, b->coord[3 * job.which],
+                                                    b->coord[3 * job.which + 1], b->coord[3 * job.which + 2], b->store, b->stream));
+      else
+        SBA_TRY_HIP(sba::launch_batch_d12_to_planes(stage, m, first, b->offsets_dev, B, b->desc_dev, ppt, b->dplane[0], b->dplane[1],
+                                                    b->stream));
+    }
+  }
+  return sba::stream_wait(b->stream, "batch upload", &b->poisoned);      // before the staging buffer goes out of scope
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +335,8 @@ int sba_batch_destroy(sba_batch* b) {
                                        "wait timed out or the device faulted); the process should exit non-zero");
   }
   free_batch_data(b);
+  for (void*& q : b->upload_pinned) { if (q) (void)hipHostFree(q); q = nullptr; }
+  for (hipEvent_t& e : b->upload_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return SBA_OK;
@@ -301,6 +360,12 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   const size_t total = num_pairs > 0 ? offsets[num_pairs] - offsets[0] : 0;
   if (total > 0 && (!left_xyz || !right_xyz)) return sba::set_error(SBA_ERR_INVALID_ARG, "null coordinate array");
   SBA_TRY_HIP(hipSetDevice(b->device));
+  // The same pairs again (same offsets, store, depths or not -- e.g. the next images of the same rig, or a re-run): the
+  // planes, the descriptors and every mapped buffer stay; only the data moves.  The padding of the planes is still zero:
+  // nothing but real elements is ever written.
+  if (b->uploaded && b->num_pairs == num_pairs && num_pairs > 0 && b->store == store && b->has_d12 == (d12 != nullptr) &&
+      std::equal(b->offsets.begin(), b->offsets.end(), offsets))
+    return batch_transfer(b, left_xyz, right_xyz, d12, 7u);
   int rc = free_batch_data(b);
   if (rc) return rc;
   b->num_pairs = num_pairs;
@@ -389,32 +454,28 @@ int sba_batch_upload(sba_batch* b, const double* left_xyz, const double* right_x
   SBA_TRY_HIP(hipMemset(b->lm_ticket, 0, 64));
   b->seq = 0;
 
-  // stage the AoS arrays whole, then re-lay each pair out at its plane offset
-  const size_t base = offsets[0];
-  if (total > 0) {
-    sba::DeviceBuffer stage_buf(&b->poisoned);
-    SBA_TRY_HIP(stage_buf.alloc(total * 3 * sizeof(double)));
-    double* stage = stage_buf.as<double>();
-    const double* src[2] = {left_xyz, right_xyz};
-    for (int side = 0; side < 2; ++side) {
-      SBA_TRY_HIP(hipMemcpyAsync(stage, src[side] + 3 * base, total * 3 * sizeof(double), hipMemcpyHostToDevice, b->stream));
-      for (int g = 0; g < num_pairs; ++g)
-        SBA_TRY_HIP(sba::launch_aos_to_planes(stage + 3 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
-                                              b->coord[3 * side], b->coord[3 * side + 1], b->coord[3 * side + 2],
-                                              store, b->stream, sba::kPairTile * ppt, b->tile_stride * ppt));
-      { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
-    }
-    if (d12) {
-      SBA_TRY_HIP(hipMemcpyAsync(stage, d12 + 2 * base, total * 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
-      for (int g = 0; g < num_pairs; ++g)
-        SBA_TRY_HIP(sba::launch_d12_to_planes(stage + 2 * (offsets[g] - base), b->n[g], b->first_vec[g] * ppt,
-                                              b->dplane[0], b->dplane[1], b->stream, sba::kPairTile * ppt, b->tile_stride * ppt));
-      { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
-    }
+  {
+    std::vector<unsigned long long> off64(num_pairs + 1);
+    for (int g = 0; g <= num_pairs; ++g) off64[g] = offsets[g] - offsets[0];
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->offsets_dev), sizeof(unsigned long long) * off64.size()));
+    SBA_TRY_HIP(hipMemcpy(b->offsets_dev, off64.data(), sizeof(unsigned long long) * off64.size(), hipMemcpyHostToDevice));
   }
-  { const int _rc = sba::stream_wait(b->stream, "stream synchronisation", &b->poisoned); if (_rc) return _rc; }
+  rc = batch_transfer(b, left_xyz, right_xyz, d12, 7u);
+  if (rc) return rc;
   b->uploaded = true;
   return SBA_OK;
+}
+
+// Only the per-match depths again (init_d): the pipeline refines them in place, the coordinates stay resident.
+int sba_batch_set_depths(sba_batch* b, const double* d12) {
+  if (!b) return sba::set_error(SBA_ERR_INVALID_ARG, "null batch handle");
+  SBA_REFUSE_POISONED(b);
+  if (!b->uploaded) return sba::set_error(SBA_ERR_NOT_UPLOADED, "no pairs uploaded");
+  if (!b->has_d12) return sba::set_error(SBA_ERR_INVALID_ARG, "the batch was uploaded without per-match depths");
+  if (b->num_pairs == 0) return SBA_OK;
+  if (!d12) return sba::set_error(SBA_ERR_INVALID_ARG, "d12 is null");
+  SBA_TRY_HIP(hipSetDevice(b->device));
+  return batch_transfer(b, nullptr, nullptr, d12, 4u);
 }
 
 int sba_batch_size(const sba_batch* b, int* num_pairs, int* blocks_per_pair) {

@@ -177,6 +177,14 @@ hipError_t launch_aos_to_planes(const double* aos, size_t n, size_t first, void*
 // d12 (double[2n]) -> two f64 planes.
 hipError_t launch_d12_to_planes(const double* d12, size_t n, size_t first, double* d1, double* d2,
                                 hipStream_t stream, size_t tile_elems = 0, size_t tile_stride_elems = 0);
+// A chunk of the CONCATENATED arrays of a batch (rows first_row .. first_row + m, relative to the batch's first row) to its
+// places in the pairs' tiles, one launch: offsets_dev[num_pairs + 1] = first row of every pair (relative likewise).
+hipError_t launch_batch_aos_to_planes(const double* aos, size_t m, size_t first_row, const unsigned long long* offsets_dev,
+                                      int num_pairs, const PairDesc* desc, size_t ppt, void* px, void* py, void* pz, int store,
+                                      hipStream_t stream);
+hipError_t launch_batch_d12_to_planes(const double* d12, size_t m, size_t first_row, const unsigned long long* offsets_dev,
+                                      int num_pairs, const PairDesc* desc, size_t ppt, double* d1, double* d2,
+                                      hipStream_t stream);
 hipError_t launch_planes_to_d12(const double* d1, const double* d2, size_t n, double* d12,
                                 hipStream_t stream);
 

@@ -31,6 +31,42 @@ __global__ void d12_to_planes_kernel(const double* __restrict__ d12, size_t n, s
   d1[o] = d.x;
   d2[o] = d.y;
 }
+// The same re-layout for a whole batch in one launch: rows [first_row, first_row + m) of the caller's CONCATENATED arrays
+// (pair g = rows offsets[g] .. offsets[g + 1]) sit in `stage`; every row finds its pair by bisection of the offsets (a few KB,
+// L2-resident) and goes to its place in the pair's tiles (PairDesc).  One launch per staged chunk instead of one per pair.
+__device__ __forceinline__ size_t batch_row_index(size_t row, const unsigned long long* __restrict__ offsets, int num_pairs,
+                                                  const PairDesc* __restrict__ desc, size_t ppt) {
+  int lo = 0, hi = num_pairs;                 // offsets[lo] <= row < offsets[hi]; empty pairs repeat an offset: the last one wins
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offsets[mid] <= row) lo = mid; else hi = mid;
+  }
+  const PairDesc d = desc[lo];
+  return tiled_index(d.first_vec * ppt, row - offsets[lo], kPairTile * ppt, d.tile_stride * ppt);
+}
+template <typename ST>
+__global__ void batch_aos_to_planes_kernel(const double* __restrict__ aos, size_t m, size_t first_row,
+                                           const unsigned long long* __restrict__ offsets, int num_pairs,
+                                           const PairDesc* __restrict__ desc, size_t ppt, ST* __restrict__ px,
+                                           ST* __restrict__ py, ST* __restrict__ pz) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const size_t o = batch_row_index(first_row + i, offsets, num_pairs, desc, ppt);
+  px[o] = static_cast<ST>(aos[3 * i + 0]);
+  py[o] = static_cast<ST>(aos[3 * i + 1]);
+  pz[o] = static_cast<ST>(aos[3 * i + 2]);
+}
+__global__ void batch_d12_to_planes_kernel(const double* __restrict__ d12, size_t m, size_t first_row,
+                                           const unsigned long long* __restrict__ offsets, int num_pairs,
+                                           const PairDesc* __restrict__ desc, size_t ppt, double* __restrict__ d1,
+                                           double* __restrict__ d2) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const double2 d = reinterpret_cast<const double2*>(d12)[i];
+  const size_t o = batch_row_index(first_row + i, offsets, num_pairs, desc, ppt);
+  d1[o] = d.x;
+  d2[o] = d.y;
+}
 __global__ void planes_to_d12_kernel(const double* __restrict__ d1, const double* __restrict__ d2,
                                      size_t n, double* __restrict__ d12) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -95,6 +131,30 @@ hipError_t launch_d12_to_planes(const double* d12, size_t n, size_t first, doubl
   if (n == 0) return hipSuccess;
   const unsigned grid = static_cast<unsigned>((n + 255) / 256);
   hipLaunchKernelGGL(d12_to_planes_kernel, dim3(grid), dim3(256), 0, stream, d12, n, first, d1, d2, tile_elems, tile_stride_elems);
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_aos_to_planes(const double* aos, size_t m, size_t first_row, const unsigned long long* offsets_dev,
+                                      int num_pairs, const PairDesc* desc, size_t ppt, void* px, void* py, void* pz, int store,
+                                      hipStream_t stream) {
+  if (m == 0 || num_pairs <= 0) return hipSuccess;
+  const unsigned grid = static_cast<unsigned>((m + 255) / 256);
+  if (store == 0)
+    hipLaunchKernelGGL((batch_aos_to_planes_kernel<double>), dim3(grid), dim3(256), 0, stream, aos, m, first_row, offsets_dev,
+                       num_pairs, desc, ppt, static_cast<double*>(px), static_cast<double*>(py), static_cast<double*>(pz));
+  else
+    hipLaunchKernelGGL((batch_aos_to_planes_kernel<float>), dim3(grid), dim3(256), 0, stream, aos, m, first_row, offsets_dev,
+                       num_pairs, desc, ppt, static_cast<float*>(px), static_cast<float*>(py), static_cast<float*>(pz));
+  return hipGetLastError();
+}
+
+hipError_t launch_batch_d12_to_planes(const double* d12, size_t m, size_t first_row, const unsigned long long* offsets_dev,
+                                      int num_pairs, const PairDesc* desc, size_t ppt, double* d1, double* d2,
+                                      hipStream_t stream) {
+  if (m == 0 || num_pairs <= 0) return hipSuccess;
+  const unsigned grid = static_cast<unsigned>((m + 255) / 256);
+  hipLaunchKernelGGL(batch_d12_to_planes_kernel, dim3(grid), dim3(256), 0, stream, d12, m, first_row, offsets_dev, num_pairs, desc,
+                     ppt, d1, d2);
   return hipGetLastError();
 }
 

@@ -42,6 +42,8 @@ hipError_t hipStreamQuery(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t*);
 hipError_t hipEventDestroy(hipEvent_t);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
+hipError_t hipEventCreateWithFlags(hipEvent_t*, unsigned);
+constexpr unsigned hipEventDisableTiming = 2;
 hipError_t hipEventSynchronize(hipEvent_t);
 hipError_t hipEventQuery(hipEvent_t);
 hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);

@@ -60,6 +60,7 @@ hipError_t hipStreamQuery(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(std::malloc(8)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventQuery(hipEvent_t) { return g_wedged ? hipErrorNotReady : hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { blocking_call("hipEventSynchronize"); return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return hipSuccess; }
@@ -105,6 +106,10 @@ hipError_t launch_batch_step(int, int, int, int, double, const Planes&, const Ba
 hipError_t launch_aos_to_planes(const double*, size_t, size_t, void*, void*, void*, int, hipStream_t, size_t, size_t) { return hipSuccess; }
 hipError_t launch_d12_to_planes(const double*, size_t, size_t, double*, double*, hipStream_t, size_t, size_t) { return hipSuccess; }
 hipError_t launch_planes_to_d12(const double*, const double*, size_t, double*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_aos_to_planes(const double*, size_t, size_t, const unsigned long long*, int, const PairDesc*, size_t, void*, void*, void*,
+                                      int, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_d12_to_planes(const double*, size_t, size_t, const unsigned long long*, int, const PairDesc*, size_t, double*, double*,
+                                      hipStream_t) { return hipSuccess; }
 hipError_t launch_depth_step(int, const Planes&, const double*, const double*, double*, double*, double*, double*, const DepthParams&, double*,
                              int, double*, double* host, unsigned long long seq, int, hipStream_t) {
   publish(host, 24, seq); return hipSuccess;

@@ -258,6 +258,64 @@ def test_batch_pipeline_matches_single_problem_pipelines(oracle, driver, monkeyp
             assert np.abs(res["rot"][g] - ro2).max() <= 1e-7 and np.abs(res["tran"][g] - to2).max() <= 1e-7
 
 
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("layout", ["0", "1"], ids=["contiguous", "interleaved"])
+def test_batch_upload_pipelined_relayout_and_reuse(store, layout, monkeypatch):
+    """sba_batch_upload moves the concatenated arrays in 16 MiB chunks through pinned staging and ONE re-layout launch per
+    chunk (every row finds its pair by bisection of the offsets): chunk boundaries fall inside pairs, empty pairs repeat an
+    offset, the batch need not start at row 0.  The planes must hold exactly what a per-pair upload of the same data holds:
+    every pair's pack equals the single-problem pack to the bit-level tolerance of the sweep, the refined depths read back
+    land at the caller's rows.  A second upload with the same offsets reuses every allocation (new data must show), and
+    sba_batch_set_depths replaces the depths alone."""
+    monkeypatch.setenv("SBA_BATCH_INTERLEAVE", layout)
+    sizes = [400_000, 0, 350_001, 0, 0, 299_999, 7, 450_000, 1, 380_000]          # 1.88 M rows: three chunks per array
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=8800)
+    lead = 1234                                                                   # the batch starts at row 1234 of the caller's arrays
+    pad3, pad2 = np.full((lead, 3), 7.0), np.full((lead, 2), 9.0)
+    X1, X2, D = np.concatenate([pad3, x1]), np.concatenate([pad3, x2]), np.concatenate([pad2, d12])
+    off2 = off + np.uint64(lead)
+    rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
+    with api.Batch(0) as b:
+        b.upload(X1, X2, off2, D, store=store)
+        packs = b.eval(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)
+        for g, c in enumerate(cs):
+            if sizes[g] == 0:
+                assert not packs[g].any()
+                continue
+            with api.Problem(0) as p:
+                p.upload(c.x1, c.x2, c.d12, store=store)
+                ref = p.eval_pack(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+            assert np.abs(packs[g] - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-300), (g, sizes[g])
+        # same offsets, other data: allocations are reused, the data must be the new one
+        D2 = D * 1.25
+        X1b = X1.copy(); X1b[lead:] = x2; X2b = X2.copy(); X2b[lead:] = x1                  # left and right swapped
+        b.upload(X1b, X2b, off2, D2, store=store)
+        packs_b = b.eval(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)
+        g = 2
+        with api.Problem(0) as p:
+            p.upload(cs[g].x2, cs[g].x1, cs[g].d12 * 1.25, store=store)
+            ref = p.eval_pack(api.MODE_RT, cs[g].rot_init, cs[g].tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        assert np.abs(packs_b[g] - ref).max() <= 1e-10 * np.abs(ref).max()
+        # depths alone
+        b.set_depths(D)
+        packs_c = b.eval(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)
+        with api.Problem(0) as p:
+            p.upload(cs[g].x2, cs[g].x1, cs[g].d12, store=store)
+            ref = p.eval_pack(api.MODE_RT, cs[g].rot_init, cs[g].tran_init, depth_mode=api.DEPTH_PER_MATCH)
+        assert np.abs(packs_c[g] - ref).max() <= 1e-10 * np.abs(ref).max()
+        # and back out: the refined depths of a d-only stage land at the caller's rows
+        d_out, sums, status = b.solve_depths(rot, tran, options=api.default_lm_options(max_num_iterations=2))
+        assert d_out.shape == D.shape and not d_out[:lead].any()
+        lo, hi = int(off2[7]), int(off2[8])
+        with api.Problem(0) as p:
+            p.upload(cs[7].x2, cs[7].x1, cs[7].d12, store=store)
+            d1, _ = p.solve_depths(cs[7].rot_init, cs[7].tran_init, options=api.default_lm_options(max_num_iterations=2))
+        assert np.abs(d_out[lo:hi] - d1).max() <= 1e-9 * max(1.0, np.abs(d1).max())
+    with api.Batch(0) as b2:
+        with pytest.raises(api.SbaError):
+            b2.set_depths(D)                                                             # nothing uploaded yet
+
+
 def test_batch_solve_matches_single_problem_solves(oracle):
     sizes = [4000, 0, 2500, 3333, 1, 5000]
     cs, off, x1, x2, d12 = _make_pairs(sizes)
