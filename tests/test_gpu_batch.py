@@ -388,6 +388,58 @@ def test_batch_config_c5_full_size_properties(oracle):
     assert np.array_equal(p2[::-1], p1)
 
 
+def test_batch_pipeline_config_c5_full_size_properties(oracle):
+    """The reference's per-pair pipeline (guess -> d-only -> rot-only -> tran-only) at BASELINE config C5's FULL size, 256
+    pairs x 50k matches, through size-independent properties: every pair is served (a candidate, three converged stages or
+    the iteration limit, finite results); a repeated run from re-sent depths is bit-identical; a pair's result does not depend
+    on where it sits in the batch (reversed order: bit-identical per pair, guess included); sampled pairs equal the
+    single-problem chain and the oracle's stages from the same start (iteration counts, R|t)."""
+    B, n = 256, 50_000
+    cs = [synthetic.full_rt(n, seed=6100 + g, sigma=2e-4, outlier_fraction=0.02) for g in range(B)]
+    off = (np.arange(B + 1) * n).astype(np.uint64)
+    x1 = np.concatenate([c.x1 for c in cs]); x2 = np.concatenate([c.x2 for c in cs])
+    d0 = np.full((B * n, 2), 6.0)
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, d0)
+        e, t, nc, st = b.initial_guess(80, 0.25, 3)
+        res = b.solve_problem(seed=3)
+        b.set_depths(d0)
+        res_again = b.solve_problem(seed=3)
+    assert (res["status"] == 0).all() and (res["guess_candidates"] >= 1).all()
+    assert np.isfinite(res["rot"]).all() and np.isfinite(res["tran"]).all() and (res["d_uniform"] > 0).all()
+    for key in ("rot", "tran", "d_uniform"):
+        assert np.array_equal(res[key], res_again[key]), key
+    for stage in ("depth_stage", "rot_stage", "tran_stage"):
+        assert all(q.termination.startswith("CONVERGENCE") or q.termination == "NO_CONVERGENCE" for q in res[stage])
+        assert [q.num_iterations for q in res[stage]] == [q.num_iterations for q in res_again[stage]]
+    assert np.median([np.abs(res["rot"][g] - cs[g].rot_true).max() for g in range(B)]) < 0.05
+    for g in (0, 131, 255):
+        c = cs[g]
+        rot0, tran0 = -e[g], t[g]
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, d0[:n])
+            d, sd = p.solve_depths(rot0, tran0)
+            r1, t1, s1 = p.solve(api.MODE_ROT, rot0, tran0, d[0, 0], d[1, 0])
+            r2, t2, s2 = p.solve(api.MODE_TRAN, r1, t1, d[0, 0], d[1, 0])
+        got = (res["depth_stage"][g].num_iterations, res["depth_stage"][g].num_line_search_steps, res["rot_stage"][g].num_iterations,
+               res["tran_stage"][g].num_iterations)
+        assert got == (sd.num_iterations, sd.num_line_search_steps, s1.num_iterations, s2.num_iterations), (g, got)
+        assert np.abs(res["rot"][g] - r2).max() <= 1e-9 and np.abs(res["tran"][g] - t2).max() <= 1e-9
+        assert res["d_uniform"][g, 0] == pytest.approx(d[0, 0], rel=1e-9) and res["d_uniform"][g, 1] == pytest.approx(d[1, 0], rel=1e-9)
+        if g == 131:
+            dd, sdd, _ = oracle.depth_solve(c.x1, c.x2, rot0, tran0, d0[:n])
+            ro, to, so, _ = oracle.lm_solve(api.MODE_ROT, c.x1, c.x2, rot0, tran0, dd[0, 0], dd[1, 0])
+            ro2, to2, so2, _ = oracle.lm_solve(api.MODE_TRAN, c.x1, c.x2, ro, to, dd[0, 0], dd[1, 0])
+            assert (sdd.num_iterations, so.num_iterations, so2.num_iterations) == (got[0], got[2], got[3])
+            assert np.abs(res["rot"][g] - ro2).max() <= 1e-7 and np.abs(res["tran"][g] - to2).max() <= 1e-7
+    order = np.arange(B)[::-1]
+    with api.Batch(0) as b:
+        b.upload(np.concatenate([cs[g].x1 for g in order]), np.concatenate([cs[g].x2 for g in order]), off, d0)
+        rev = b.solve_problem(seed=3)
+    assert np.array_equal(rev["rot"][::-1], res["rot"]) and np.array_equal(rev["tran"][::-1], res["tran"])
+    assert np.array_equal(rev["guess_candidates"][::-1], res["guess_candidates"])
+
+
 @pytest.mark.parametrize("kind", [api.KERNEL_FACTORED, api.KERNEL_EXPLICIT], ids=["factored", "explicit"])
 @pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
 def test_one_block_per_pair_paths_equal_the_chain_and_the_oracle(oracle, kind, store):
