@@ -6,6 +6,7 @@ Jacobian evaluation over them, the *solve stage* is the LM loop of ``solve_probl
 from __future__ import annotations
 
 import ctypes as C
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -505,13 +506,16 @@ class Batch:
         du = np.zeros((max(B, 1), 2))
         nc, status = np.zeros(max(B, 1), dtype=np.int32), np.zeros(max(B, 1), dtype=np.int32)
         sums = [(cabi.LmSummary * max(B, 1))() for _ in range(3)]
+        t0 = time.perf_counter()
         rc = self._lib.sba_batch_solve_problem(self._h, 1 if use_initial_guess else 0, trials, subset_fraction, seed, _dptr(r), _dptr(t),
                                                C.byref(opt), d12.ctypes.data_as(C.c_void_p) if want_depths else None, _dptr(du),
                                                nc.ctypes.data_as(C.POINTER(C.c_int)), sums[0], sums[1], sums[2],
                                                status.ctypes.data_as(C.POINTER(C.c_int)))
+        seconds = time.perf_counter() - t0       # the library call alone (the summaries below are 3 B Python objects)
         if check or rc != cabi.SBA_ERR_NUMERIC:
             cabi.check(self._lib, rc)
         return {"rot": r[:B], "tran": t[:B], "d_uniform": du[:B], "guess_candidates": nc[:B], "status": status[:B], "d12": d12,
+                "seconds_inside_the_library": seconds,
                 "depth_stage": [_summary(sums[0][i]) for i in range(B)], "rot_stage": [_summary(sums[1][i]) for i in range(B)],
                 "tran_stage": [_summary(sums[2][i]) for i in range(B)]}
 

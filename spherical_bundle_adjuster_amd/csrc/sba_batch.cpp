@@ -633,10 +633,11 @@ int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran,
     std::memset(b->depth_out_host, 0, sizeof(double) * (static_cast<size_t>(B) * sba::DEPTH_ROW + 8));
     SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->depth_out_host_dev), b->depth_out_host, 0));
     b->depth_seq = 0;
+    // candidate + scaling planes start zeroed, once: a candidate plane becomes a pair's depth plane when a step is accepted,
+    // and its padding must be zeros like the uploaded planes' -- the passes only ever write real elements (and zeros into the
+    // padding element of an odd-sized pair), so the padding stays zero from stage to stage
+    SBA_TRY_HIP(hipMemsetAsync(b->depth_work, 0, 4 * elems * sizeof(double), b->stream));
   }
-  // candidate + scaling planes start zeroed: a candidate plane becomes a pair's depth plane when a step is accepted, and its
-  // padding must be zeros like the uploaded planes'
-  SBA_TRY_HIP(hipMemsetAsync(b->depth_work, 0, 4 * elems * sizeof(double), b->stream));
   double *w1 = b->depth_work, *w2 = w1 + elems, *sc1 = w1 + 2 * elems, *sc2 = w1 + 3 * elems;
   std::vector<sba::BatchDepthConst> cst(B);
   for (int g = 0; g < B; ++g) {
