@@ -321,6 +321,10 @@ def run_c5(a):
                                 res["rot_stage"][g].num_iterations, res["tran_stage"][g].num_iterations)
             pipeline = {"seconds": p_s, "seconds_with_the_python_wrapper": float(np.median(times)), "pairs_per_s": B / p_s,
                         "pairs_ok": int((res["status"] == 0).sum()),
+                        "iterations_min_median_max": {k: [int(np.min(v)), float(np.median(v)), int(np.max(v))] for k, v in
+                                                      ((st, [q.num_iterations for q in res[st]]) for st in ("depth_stage", "rot_stage", "tran_stage"))},
+                        "evaluations_sum_and_max": {k: [int(np.sum(v)), int(np.max(v))] for k, v in
+                                                    ((st, [q.num_evaluations for q in res[st]]) for st in ("depth_stage", "rot_stage", "tran_stage"))},
                         "what": "sba_batch_solve_problem: 8-point consensus guess, d-only, rot-only, tran-only for all pairs "
                                 "(start d = 6); depths already resident; the C call alone, median of 5 (the Python wrapper then builds "
                                 "3 x 256 summary objects)"}

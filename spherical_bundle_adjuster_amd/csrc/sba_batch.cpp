@@ -71,6 +71,17 @@ struct sba_batch {
   double* epi_groups_host = nullptr;          // pinned
   sba::BatchGuessOut* guess_out_dev = nullptr;
   sba::BatchGuessOut* guess_out_host = nullptr;   // pinned
+  // device-resident solves with dynamic shares (allocated on first use)
+  sba::BatchDynCtl* dyn_ctl = nullptr;
+  unsigned int* dyn_active = nullptr;        // [2][num_pairs]
+  int* dyn_done = nullptr;                   // [num_pairs]
+  void* dyn_state = nullptr;                 // per-pair solver state
+  size_t dyn_state_bytes = 0;
+  double* dyn_partials = nullptr;            // share rows of one launch
+  size_t dyn_partial_rows = 0;
+  unsigned long long* dyn_host = nullptr;    // pinned + mapped: [0] pairs still active, [1] sequence word
+  unsigned long long* dyn_host_dev = nullptr;
+  unsigned long long dyn_seq = 0;
   // upload: row offsets on the device (relative to the first row), two pinned staging buffers, their DMA-done events
   unsigned long long* offsets_dev = nullptr;
   void* upload_pinned[2] = {nullptr, nullptr};
@@ -100,6 +111,14 @@ int free_batch_data(sba_batch* b) {
   if (b->epi_groups_host) SBA_TRY_HIP(hipHostFree(b->epi_groups_host));
   if (b->offsets_dev) SBA_TRY_HIP(hipFree(b->offsets_dev));
   b->offsets_dev = nullptr;
+  if (b->dyn_ctl) SBA_TRY_HIP(hipFree(b->dyn_ctl));
+  if (b->dyn_active) SBA_TRY_HIP(hipFree(b->dyn_active));
+  if (b->dyn_done) SBA_TRY_HIP(hipFree(b->dyn_done));
+  if (b->dyn_state) SBA_TRY_HIP(hipFree(b->dyn_state));
+  if (b->dyn_partials) SBA_TRY_HIP(hipFree(b->dyn_partials));
+  if (b->dyn_host) SBA_TRY_HIP(hipHostFree(b->dyn_host));
+  b->dyn_ctl = nullptr; b->dyn_active = nullptr; b->dyn_done = nullptr; b->dyn_state = nullptr; b->dyn_state_bytes = 0;
+  b->dyn_partials = nullptr; b->dyn_partial_rows = 0; b->dyn_host = nullptr; b->dyn_host_dev = nullptr; b->dyn_seq = 0;
   if (b->guess_out_dev) SBA_TRY_HIP(hipFree(b->guess_out_dev));
   if (b->guess_out_host) SBA_TRY_HIP(hipHostFree(b->guess_out_host));
   b->epi_groups_dev = nullptr; b->epi_groups_host = nullptr; b->guess_out_dev = nullptr; b->guess_out_host = nullptr;
@@ -229,6 +248,34 @@ class PairWorkers {
   std::atomic<int> done_{0};
   std::atomic<bool> quit_{false};
 };
+
+// Buffers of the device-resident solves with dynamic shares; state_bytes: per-pair solver state of the stage that asks.
+int ensure_dyn(sba_batch* b, size_t state_bytes, size_t partial_rows) {
+  const size_t B = static_cast<size_t>(b->num_pairs);
+  if (!b->dyn_ctl) {
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_ctl), sizeof(sba::BatchDynCtl)));
+    SBA_TRY_HIP(hipMemsetAsync(b->dyn_ctl, 0, sizeof(sba::BatchDynCtl), b->stream));      // stream-ordered: never a blocking call here
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_active), sizeof(unsigned int) * 2 * B));
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_done), sizeof(int) * B));
+    SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dyn_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(b->dyn_host, 0, 64);
+    SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->dyn_host_dev), b->dyn_host, 0));
+    b->dyn_seq = 0;
+  }
+  if (b->dyn_state_bytes < state_bytes * B) {
+    if (b->dyn_state) SBA_TRY_HIP(hipFree(b->dyn_state));
+    b->dyn_state = nullptr; b->dyn_state_bytes = 0;
+    SBA_TRY_HIP(hipMalloc(&b->dyn_state, state_bytes * B));
+    b->dyn_state_bytes = state_bytes * B;
+  }
+  if (b->dyn_partial_rows < partial_rows) {
+    if (b->dyn_partials) SBA_TRY_HIP(hipFree(b->dyn_partials));
+    b->dyn_partials = nullptr; b->dyn_partial_rows = 0;
+    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_partials), partial_rows * sba::kRow * sizeof(double)));
+    b->dyn_partial_rows = partial_rows;
+  }
+  return SBA_OK;
+}
 
 // Host arrays -> planes.  The caller's arrays are pageable (std::vector<cv::Point3d>::data() of many image pairs, or numpy):
 // as for a large single problem (sba_shim.cpp: upload_common) a few host threads copy chunk k + 1 into one of two pinned
@@ -915,7 +962,17 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
   // which also serves batches that spread a pair over several blocks.
   bool device_lm = b->bpp == 1;
   if (const char* env = std::getenv("SBA_BATCH_DEVICE_LM")) device_lm = device_lm && std::strcmp(env, "0") != 0;
-  if (device_lm) {
+  // Device-resident LM with DYNAMIC shares (one launch triple per iteration, the blocks dealt out to the pairs that are still
+  // iterating): serves any number of blocks per pair.  SBA_BATCH_DYNAMIC=1 selects it (see DESIGN.md section 3.5 for when it wins).
+  // Default with one block per pair (hybrid): the one-launch kernel runs the first sweeps of every pair -- enough for most --
+  // and hands the pairs that need more over to the dynamic launches, where the CUs of the finished pairs join in.
+  // SBA_BATCH_DYNAMIC=1: dynamic launches from the first sweep (any number of blocks per pair); =0: the one-launch kernel to
+  // the end.  SBA_BATCH_LM_FIRST_SWEEPS: the cap of the first launch (default 6).
+  bool dynamic = false, hybrid = device_lm && b->publish;
+  if (const char* env = std::getenv("SBA_BATCH_DYNAMIC")) { dynamic = b->publish && std::strcmp(env, "0") != 0; hybrid = false; }
+  int first_sweeps = 6;
+  if (const char* env = std::getenv("SBA_BATCH_LM_FIRST_SWEEPS")) { const int v = std::atoi(env); if (v >= 1 && v <= 1000) first_sweeps = v; }
+  if (device_lm || dynamic) {
     const auto t0 = std::chrono::steady_clock::now();
     // start points go to the device through mapped pinned memory (thread 0 of every block reads its own record once,
     // and writes the result back there at the end): no allocation, no copies -- one launch and one synchronise
@@ -934,12 +991,59 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
     // completion word: the slot after the packs in the mapped host buffer (the same one the batched step publishes to)
     volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(b->packs_host + 24 * B);
     unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(b->packs_host_dev + 24 * B);
-    if (b->publish) {
+    // The remaining iterations as launches with dynamic shares, enqueued in groups of four without waiting; after each group
+    // the host learns from the compaction kernel's publication how many pairs are still iterating.  A launch without active
+    // pairs is three empty kernels.  first_parity: which active list the first pass reads.
+    int per_cu = 1;
+    if (const char* env = std::getenv("SBA_BATCH_DYN_BLOCKS_PER_CU")) { const int v = std::atoi(env); if (v >= 1 && v <= 8) per_cu = v; }
+    const int sweep_grid = std::max(1, b->num_cus * per_cu);
+    auto run_dynamic = [&](int first_parity, unsigned long long remaining) -> int {
+      const int max_passes = std::max(0, o.max_num_iterations) + 8;
+      volatile unsigned long long* words = b->dyn_host;
+      int pass = 0;
+      while (remaining > 0 && pass < max_passes) {
+        const int group = std::min(4, max_passes - pass);
+        unsigned long long seq = 0;
+        for (int k = 0; k < group; ++k, ++pass) {
+          const bool last = k == group - 1;
+          if (last) seq = ++b->dyn_seq;
+          SBA_TRY_HIP(sba::launch_batch_lm_dyn_pass(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, o, B, (first_parity + pass) & 1,
+                                                    sweep_grid, b->dyn_state, b->params_dev, b->frames_dev, b->dyn_ctl, b->dyn_active,
+                                                    b->dyn_done, b->dyn_partials, b->lm_io_host_dev, last ? b->dyn_host_dev : nullptr, seq,
+                                                    b->stream));
+        }
+        const int wrc = sba::wait_for_sequence(words + 1, seq, b->stream, "batched per-pair solve (dynamic shares)", &b->poisoned);
+        if (wrc) return wrc;
+        remaining = words[0];
+      }
+      return SBA_OK;      // pairs that ran out of launches keep SBA_ERR_NUMERIC (cannot happen: the solver's limit ends it first)
+    };
+    if (dynamic || hybrid) {
+      const int rc2 = ensure_dyn(b, sba::batch_lm_dyn_state_bytes(), static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
+      if (rc2) return rc2;
+    }
+    if (dynamic) {
+      SBA_TRY_HIP(sba::launch_batch_lm_dyn_init(mode, depth_mode, b->kind, b->desc_dev, b->lm_io_host_dev, o, B, b->dyn_state,
+                                                b->params_dev, b->frames_dev, b->dyn_ctl, b->dyn_active, b->dyn_done, b->stream));
+      const int rc2 = run_dynamic(0, static_cast<unsigned long long>(B));
+      if (rc2) return rc2;
+    } else if (b->publish) {
+      // One launch for the first sweeps of every pair (hybrid: at most first_sweeps of them; all of them otherwise) ...
       const unsigned long long seq = ++b->seq;
       SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B,
-                                       b->lm_ticket, flag_dev, seq, b->stream));
+                                       b->lm_ticket, flag_dev, seq, b->stream, hybrid ? first_sweeps : 0, hybrid ? b->dyn_state : nullptr,
+                                       hybrid ? b->params_dev : nullptr, hybrid ? b->frames_dev : nullptr, hybrid ? b->dyn_done : nullptr));
       const int wrc = sba::wait_for_sequence(flag, seq, b->stream, "batched per-pair solve", &b->poisoned);
       if (wrc) return wrc;
+      // ... and the pairs it handed over (record.pad_ == 1) go on with dynamic shares: their CUs are joined by those of the
+      // pairs that are done.
+      unsigned long long left = 0;
+      for (int g = 0; g < B; ++g) if (io[g].pad_ == 1) { ++left; io[g].status = SBA_ERR_NUMERIC; }
+      if (left > 0) {
+        SBA_TRY_HIP(sba::launch_batch_dyn_first_list(b->dyn_ctl, b->dyn_active, b->dyn_done, B, b->stream));
+        const int rc2 = run_dynamic(1, left);
+        if (rc2) return rc2;
+      }
     } else {
       SBA_TRY_HIP(sba::launch_batch_lm(mode, depth_mode, b->store, b->kind, pl, b->desc_dev, b->lm_io_host_dev, o, B,
                                        b->lm_ticket, nullptr, 0, b->stream));

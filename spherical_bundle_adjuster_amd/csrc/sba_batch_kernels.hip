@@ -16,17 +16,11 @@ namespace {
 // partials are folded per pair by batch_finalize_kernel.  A pair with n == 0 (e.g. already converged) costs its
 // blocks only the row store.
 template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
-__global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const SweepParams* __restrict__ params,
-                                                            const PairDesc* __restrict__ desc, int bpp,
-                                                            double* __restrict__ partials) {
+__device__ __forceinline__ void sweep_share_rows(const Planes& pl, const SweepParams* __restrict__ P, const PairDesc& dsc, unsigned j,
+                                                 unsigned bpp, double* __restrict__ wave_out, double* __restrict__ row) {
   constexpr int NACC = AccMap<MODE, KIND>::N;
   constexpr int PPT = Lanes<ST>::PPT;
-  __shared__ double lds[(kBlock / 64) * 24];
-  double* wave_out = lds;
   const int tid = threadIdx.x;
-  const unsigned pair = blockIdx.x / static_cast<unsigned>(bpp), j = blockIdx.x % static_cast<unsigned>(bpp);
-  const SweepParams* __restrict__ P = params + pair;
-  const PairDesc dsc = desc[pair];
   const size_t n = P->n;
   const size_t stride = static_cast<size_t>(bpp) * kBlock;
   static_assert(kBlock == kPairTile, "a block sweeps one 256-vector tile per trip");
@@ -49,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const Sw
     cur = nxt;
     p = pn;
   }
-  if (nfull * PPT != n && j == static_cast<unsigned>(bpp) - 1 && tid == kBlock - 1) {
+  if (nfull * PPT != n && j == bpp - 1 && tid == kBlock - 1) {
     cur.load(pl, pair_vector(dsc, nfull));
     consume<MODE, DEPTH, ST, KIND, LOSS, true>(cur, P, nfull, n, acc);
   }
@@ -76,7 +70,39 @@ __global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const Sw
 #pragma unroll
       for (int wv = 1; wv < kBlock / 64; ++wv) s += wave_out[wv * 24 + tid];
     }
-    partials[static_cast<size_t>(blockIdx.x) * kRow + tid] = s;
+    row[tid] = s;
+  }
+}
+
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void batch_sweep_kernel(Planes pl, const SweepParams* __restrict__ params,
+                                                            const PairDesc* __restrict__ desc, int bpp,
+                                                            double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / 64) * 24];
+  const unsigned pair = blockIdx.x / static_cast<unsigned>(bpp), j = blockIdx.x % static_cast<unsigned>(bpp);
+  sweep_share_rows<MODE, DEPTH, ST, KIND, LOSS>(pl, params + pair, desc[pair], j, static_cast<unsigned>(bpp), lds,
+                                                partials + static_cast<size_t>(blockIdx.x) * kRow);
+}
+
+// ---- DYNAMIC shares (sba_batch_solve, device-resident): the blocks of a launch are dealt out to the pairs that are still
+// iterating.  ctl->nactive[parity] pairs are listed in active[parity * num_pairs ...]; with G = gridDim.x blocks every active
+// pair gets S = G / nactive shares (1 when there are more pairs than blocks: a block then takes several pairs in turn), share
+// j of S sweeps the pair's tiles j, j + S, ... exactly like block j of bpp = S above, and leaves its row at
+// partials[(slot * S + j) * kRow].  Pairs that have converged cost nothing any more and their CUs work for the others.
+template <int MODE, int DEPTH, typename ST, int KIND, bool LOSS>
+__global__ __launch_bounds__(kBlock) void batch_sweep_dyn_kernel(Planes pl, const SweepParams* __restrict__ params,
+                                                                const PairDesc* __restrict__ desc,
+                                                                const BatchDynCtl* __restrict__ ctl,
+                                                                const unsigned int* __restrict__ active, int parity, int num_pairs,
+                                                                double* __restrict__ partials) {
+  __shared__ double lds[(kBlock / 64) * 24];
+  const unsigned na = ctl->nactive[parity], G = gridDim.x;
+  const unsigned S = dyn_shares(na, G);
+  for (unsigned item = blockIdx.x; item < na * S; item += G) {      // na comes from memory every block reads alike: block-uniform
+    const unsigned slot = item / S, j = item - slot * S;
+    const unsigned pair = active[static_cast<size_t>(parity) * num_pairs + slot];
+    sweep_share_rows<MODE, DEPTH, ST, KIND, LOSS>(pl, params + pair, desc[pair], j, S, lds, partials + static_cast<size_t>(item) * kRow);
+    __syncthreads();                                                // the LDS scratch is reused by the next item
   }
 }
 
@@ -308,6 +334,29 @@ __global__ __launch_bounds__(kBlock) void batch_step_kernel(Planes pl, const Pai
   }
 }
 
+// Per-pair solver state that outlives a launch (device memory): the one-launch kernel below hands a pair that has not
+// converged within its first sweeps over to the launches with dynamic shares further down.
+struct BatchLmDynState {
+  LmSolver solver;
+  double depth[2];
+};
+static_assert(sizeof(LmSolver) % 8 == 0 && sizeof(BatchLmDynState) % 8 == 0, "copied as 8-byte words");
+struct BatchLmCont {          // where batch_lm_kernel leaves the pairs it does not finish (all null: it runs every pair to the end)
+  BatchLmDynState* state;
+  SweepParams* params;
+  double* frames;
+  int* done;
+};
+
+__device__ __forceinline__ void dyn_next_sweep(int mode, int depth_mode, int kind, unsigned long long n, const LmSolver* solver,
+                                               const double depth[2], double huber_delta, SweepParams* __restrict__ params,
+                                               double* __restrict__ frames) {
+  SweepParams prm;
+  fill_sweep_params(n, depth_mode, solver->query_rot(), solver->query_tran(), depth[0], depth[1], huber_delta, &prm, kind == KIND_EXPLICIT);
+  *params = prm;
+  if (kind == KIND_FACTORED && mode != MODE_TRAN) factored_frame(solver->query_rot(), frames, frames + 9);
+}
+
 // ---- the whole per-pair solve in ONE launch ---------------------------------------------------------------------
 // With one block per pair (bpp == 1: at least one pair per CU, config C5) a pair's sweep is reduced completely inside
 // its block, so nothing about its Levenberg-Marquardt iteration needs another block -- or the host.  Block g runs pair
@@ -323,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
                                                          BatchLmIo* __restrict__ io, sba_lm_options opt,
                                                          unsigned int* __restrict__ ticket,
                                                          unsigned long long* __restrict__ seq_host,
-                                                         unsigned long long seq) {
+                                                         unsigned long long seq, int sweep_cap, BatchLmCont cont) {
   __shared__ double wave_out[(kBlock / 64) * 24];
   __shared__ double raw_s[24];
   __shared__ SweepParams prm_s;
@@ -358,8 +407,10 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
   //   * every thread takes the exit decision from the LDS word `done_s`, read after B1.
   // tests/test_isa_checks_cpu.py remains as the second line: all four barriers at loop depth 1 in every instantiation,
   // with the Makefile's flags and with the profiling variants.  The solver needs at most max_num_iterations + 1 sweeps.
-  const int max_trips = opt.max_num_iterations + 8;
-  for (int trip = 0; trip < max_trips; ++trip) {
+  // sweep_cap > 0 (with `cont`): at most that many sweeps in this launch; a pair that needs more is handed over below.
+  const int full_trips = opt.max_num_iterations + 8;
+  const int max_trips = sweep_cap > 0 && sweep_cap < full_trips ? sweep_cap : full_trips;
+  for (int trip = 0; trip <= max_trips; ++trip) {    // the trip after the last sweep only feeds its sums (and breaks below)
     __syncthreads();                        // B0: the previous trip's sums (raw_s) are complete
     if (tid == 0) {
 #ifdef SBA_LM_PROFILE
@@ -386,11 +437,25 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
       SBA_TICK(tk_prep);
     }
     __syncthreads();                        // B1: done_s / the next sweep state are visible to the block
-    if (done_s) break;
+    if (done_s || trip == max_trips) break;      // both block-uniform: an LDS word read after B1, the trip counter
     const SweepParams prm = prm_s;        // LDS broadcast -> registers, held across the sweep
     block_sweep_fold<MODE, DEPTH, ST, KIND, LOSS>(pl, dsc, n, prm, wave_out, raw_s);   // two barriers, the last one at its end
   }
   if (tid == 0) {
+    // The sweep cap ended the loop: the last trip fed the last sweep's sums and, the pair being not done, left the state of its
+    // next sweep in prm_s / frame_s.  Solver, depths and that state go to device memory for the launches with dynamic shares
+    // (batch_sweep_dyn_kernel / batch_lm_dyn_feed_kernel).
+    bool handed_over = false;
+    if (!done_s && cont.state) {
+      BatchLmDynState* out = cont.state + pair;
+      for (unsigned k = 0; k < sizeof(LmSolver) / 8; ++k) reinterpret_cast<double*>(&out->solver)[k] = reinterpret_cast<const double*>(solver_mem)[k];
+      out->depth[0] = depth_s[0]; out->depth[1] = depth_s[1];
+      cont.params[pair] = prm_s;
+      if (KIND == KIND_FACTORED && MODE != MODE_TRAN)
+        for (int k = 0; k < 18; ++k) cont.frames[18 * pair + k] = frame_s[k];
+      handed_over = true;
+    }
+    if (cont.done) cont.done[pair] = handed_over ? 0 : 1;
     BatchLmIo res;
     for (int a = 0; a < 3; ++a) { res.rot[a] = solver->rot()[a]; res.tran[a] = solver->tran()[a]; }
     res.d1 = depth_s[0]; res.d2 = depth_s[1];
@@ -401,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void batch_lm_kernel(Planes pl, const PairD
     res.summary.final_gradient_max_norm = static_cast<double>(tk_conv); res.summary.final_radius = static_cast<double>(tk_feed);
 #endif
     res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // max_trips ran out: cannot happen, but never silent
-    res.pad_ = 0;
+    res.pad_ = handed_over ? 1 : 0;                                       // 1: the pair continues in the dynamic launches
     io[pair] = res;
     // Completion: this block's record is in host memory (system-scope release + vmcnt(0)) before it takes a ticket; the
     // block that takes the last ticket re-arms the counter and stores the sequence word the host polls -- no stream
@@ -471,6 +536,137 @@ __global__ __launch_bounds__(kBlock) void resident_sweep_kernel(Planes pl, unsig
   }
 }
 
+// ---- device-resident per-pair LM with dynamic shares: the kernels around batch_sweep_dyn_kernel ------------------------------
+// Per LM iteration three launches, all enqueued by the host without waiting: the sweep above, batch_lm_dyn_feed_kernel (one
+// wave per active pair: fold the pair's share rows in share order, feed the pair's LmSolver -- copied into LDS for the step
+// and back --, write the next sweep state or the result) and batch_dyn_compact_kernel (one block: the pairs that are not done
+// yet, in order, become the other parity's active list; publishes their number to the host when asked).  Kernel boundaries
+// are the only synchronisation: no block ever waits for another.
+__global__ __launch_bounds__(64) void batch_lm_dyn_init_kernel(int mode, int depth_mode, int kind, const PairDesc* __restrict__ desc,
+                                                               const BatchLmIo* __restrict__ io, sba_lm_options opt, int num_pairs,
+                                                               BatchLmDynState* __restrict__ state, SweepParams* __restrict__ params,
+                                                               double* __restrict__ frames, BatchDynCtl* __restrict__ ctl,
+                                                               unsigned int* __restrict__ active, int* __restrict__ done) {
+  __shared__ alignas(16) unsigned char mem[sizeof(BatchLmDynState)];
+  BatchLmDynState* st = reinterpret_cast<BatchLmDynState*>(mem);
+  const unsigned pair = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    const BatchLmIo in = io[pair];           // mapped host memory: the pair's start point
+    new (&st->solver) LmSolver();
+    st->solver.start(mode, in.rot, in.tran, opt);
+    st->depth[0] = in.d1; st->depth[1] = in.d2;
+    dyn_next_sweep(mode, depth_mode, kind, desc[pair].n, &st->solver, st->depth, opt.huber_delta, params + pair, frames + 18 * pair);
+    done[pair] = 0;
+    active[pair] = pair;
+    if (pair == 0) { ctl->nactive[0] = static_cast<unsigned>(num_pairs); ctl->nactive[1] = 0u; }
+  }
+  __syncthreads();
+  for (unsigned k = lane; k < sizeof(BatchLmDynState) / 8; k += 64)
+    reinterpret_cast<double*>(state + pair)[k] = reinterpret_cast<const double*>(mem)[k];
+}
+
+__global__ __launch_bounds__(64) void batch_lm_dyn_feed_kernel(int mode, int depth_mode, int kind, const PairDesc* __restrict__ desc,
+                                                               sba_lm_options opt, int num_pairs, int parity, unsigned sweep_grid,
+                                                               const BatchDynCtl* __restrict__ ctl,
+                                                               const unsigned int* __restrict__ active,
+                                                               const double* __restrict__ partials,
+                                                               BatchLmDynState* __restrict__ state, SweepParams* __restrict__ params,
+                                                               double* __restrict__ frames, BatchLmIo* __restrict__ io,
+                                                               int* __restrict__ done) {
+  __shared__ alignas(16) unsigned char mem[sizeof(BatchLmDynState)];
+  __shared__ double raw_s[24];
+  BatchLmDynState* st = reinterpret_cast<BatchLmDynState*>(mem);
+  const int lane = threadIdx.x;
+  const unsigned na = ctl->nactive[parity];
+  const unsigned S = dyn_shares(na, sweep_grid);
+  for (unsigned slot = blockIdx.x; slot < na; slot += gridDim.x) {
+    const unsigned pair = active[static_cast<size_t>(parity) * num_pairs + slot];
+    for (unsigned k = lane; k < sizeof(BatchLmDynState) / 8; k += 64)
+      reinterpret_cast<double*>(mem)[k] = reinterpret_cast<const double*>(state + pair)[k];
+    if (lane < 24) {                                  // the pair's share rows, in share order
+      const double* rows = partials + static_cast<size_t>(slot) * S * kRow + lane;
+      double sum = rows[0];
+      for (unsigned j = 1; j < S; ++j) sum += rows[static_cast<size_t>(j) * kRow];
+      raw_s[lane] = sum;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      double pack[24];
+      if (kind == KIND_FACTORED && mode != MODE_TRAN)
+        moments_to_normal_pack(true, mode == MODE_RT, frames + 18 * pair, frames + 18 * pair + 9, raw_s, pack);
+      else
+        for (int k = 0; k < 24; ++k) pack[k] = raw_s[k];
+      sba_normal_eq ne;
+      expand_pack(mode, pack, &ne);
+      st->solver.feed(ne);
+      if (st->solver.done()) {
+        BatchLmIo res;
+        for (int a = 0; a < 3; ++a) { res.rot[a] = st->solver.rot()[a]; res.tran[a] = st->solver.tran()[a]; }
+        res.d1 = st->depth[0]; res.d2 = st->depth[1];
+        res.summary = st->solver.summary();
+        res.status = st->solver.status();
+        res.pad_ = 0;
+        io[pair] = res;                               // mapped host memory; the host reads it after the last publication
+        done[pair] = 1;
+      } else {
+        dyn_next_sweep(mode, depth_mode, kind, desc[pair].n, &st->solver, st->depth, opt.huber_delta, params + pair, frames + 18 * pair);
+      }
+    }
+    __syncthreads();
+    for (unsigned k = lane; k < sizeof(LmSolver) / 8; k += 64)
+      reinterpret_cast<double*>(state + pair)[k] = reinterpret_cast<const double*>(mem)[k];
+    __syncthreads();                                  // mem / raw_s are reused by the next slot
+  }
+}
+
+__global__ __launch_bounds__(256) void batch_dyn_identity_kernel(BatchDynCtl* __restrict__ ctl, unsigned int* __restrict__ active,
+                                                                 int num_pairs) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < static_cast<unsigned>(num_pairs)) active[i] = i;
+  if (i == 0) { ctl->nactive[0] = static_cast<unsigned>(num_pairs); ctl->nactive[1] = 0u; }
+}
+
+// One block: active[parity] minus the pairs that are done -> active[parity ^ 1], order kept.  host_words (may be null):
+// mapped host memory, [0] <- pairs still active, then [1] <- seq (the host polls [1]).
+__global__ __launch_bounds__(256) void batch_dyn_compact_kernel(BatchDynCtl* __restrict__ ctl, unsigned int* __restrict__ active,
+                                                                const int* __restrict__ done, int num_pairs, int parity,
+                                                                unsigned long long* __restrict__ host_words,
+                                                                unsigned long long seq) {
+  __shared__ unsigned int count_s[256];
+  __shared__ unsigned int total_s;
+  const unsigned tid = threadIdx.x;
+  const unsigned na = ctl->nactive[parity];
+  const unsigned per = (na + 255u) / 256u;
+  const unsigned lo = min(na, tid * per), hi = min(na, lo + per);
+  const unsigned int* src = active + static_cast<size_t>(parity) * num_pairs;
+  unsigned int* dst = active + static_cast<size_t>(parity ^ 1) * num_pairs;
+  unsigned cnt = 0;
+  for (unsigned i = lo; i < hi; ++i) cnt += done[src[i]] ? 0u : 1u;
+  count_s[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned run = 0;
+    for (int t = 0; t < 256; ++t) { const unsigned c = count_s[t]; count_s[t] = run; run += c; }
+    total_s = run;
+  }
+  __syncthreads();
+  unsigned o = count_s[tid];
+  for (unsigned i = lo; i < hi; ++i) {
+    const unsigned pair = src[i];
+    if (!done[pair]) dst[o++] = pair;
+  }
+  if (tid == 0) {
+    ctl->nactive[parity ^ 1] = total_s;
+    if (host_words) {
+      __hip_atomic_store(host_words, static_cast<unsigned long long>(total_s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(host_words + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // ---- batch kernel table (same template axes as the single-problem sweep) ---------------------------------------
 typedef void (*BatchFn)(Planes, const SweepParams*, const PairDesc*, int, double*);
 template <int MODE, int DEPTH, typename ST, int KIND>
@@ -499,7 +695,7 @@ BatchFn bpick(int mode, int depth, int store, int kind, bool loss) {
 }
 
 typedef void (*BatchLmFn)(Planes, const PairDesc*, BatchLmIo*, sba_lm_options, unsigned int*, unsigned long long*,
-                          unsigned long long);
+                          unsigned long long, int, BatchLmCont);
 template <int MODE, int DEPTH, typename ST, int KIND>
 BatchLmFn lpick_loss(bool loss) {
   return loss ? batch_lm_kernel<MODE, DEPTH, ST, KIND, true> : batch_lm_kernel<MODE, DEPTH, ST, KIND, false>;
@@ -579,6 +775,31 @@ BatchStepFn spick(int mode, int depth, int store, int kind, bool loss) {
   return nullptr;
 }
 
+typedef void (*BatchDynFn)(Planes, const SweepParams*, const PairDesc*, const BatchDynCtl*, const unsigned int*, int, int, double*);
+template <int MODE, int DEPTH, typename ST, int KIND>
+BatchDynFn dpick_loss(bool loss) {
+  return loss ? batch_sweep_dyn_kernel<MODE, DEPTH, ST, KIND, true> : batch_sweep_dyn_kernel<MODE, DEPTH, ST, KIND, false>;
+}
+template <int MODE, int DEPTH, typename ST>
+BatchDynFn dpick_kind(int kind, bool loss) {
+  return kind == KIND_EXPLICIT ? dpick_loss<MODE, DEPTH, ST, KIND_EXPLICIT>(loss) : dpick_loss<MODE, DEPTH, ST, KIND_FACTORED>(loss);
+}
+template <int MODE, int DEPTH>
+BatchDynFn dpick_store(int store, int kind, bool loss) {
+  return store == 0 ? dpick_kind<MODE, DEPTH, double>(kind, loss) : dpick_kind<MODE, DEPTH, float>(kind, loss);
+}
+BatchDynFn dpick(int mode, int depth, int store, int kind, bool loss) {
+  switch (mode * 2 + depth) {
+    case 0: return dpick_store<MODE_ROT, DEPTH_UNIFORM>(store, kind, loss);
+    case 1: return dpick_store<MODE_ROT, DEPTH_PER_MATCH>(store, kind, loss);
+    case 2: return dpick_store<MODE_TRAN, DEPTH_UNIFORM>(store, KIND_FACTORED, loss);
+    case 3: return dpick_store<MODE_TRAN, DEPTH_PER_MATCH>(store, KIND_FACTORED, loss);
+    case 4: return dpick_store<MODE_RT, DEPTH_UNIFORM>(store, kind, loss);
+    case 5: return dpick_store<MODE_RT, DEPTH_PER_MATCH>(store, kind, loss);
+  }
+  return nullptr;
+}
+
 }  // namespace
 
 hipError_t launch_batch_step_fused(int mode, int depth, int store, int kind, double huber_delta, const Planes& pl,
@@ -594,12 +815,24 @@ hipError_t launch_batch_step_fused(int mode, int depth, int store, int kind, dou
 
 hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
                            BatchLmIo* io, const sba_lm_options& opt, int num_pairs, unsigned int* ticket,
-                           unsigned long long* seq_host_dev, unsigned long long seq, hipStream_t stream) {
+                           unsigned long long* seq_host_dev, unsigned long long seq, hipStream_t stream, int sweep_cap,
+                           void* cont_state, SweepParams* cont_params, double* cont_frames, int* cont_done) {
   if (num_pairs <= 0) return hipSuccess;
   BatchLmFn fn = lpick(mode, depth, store, kind, opt.huber_delta > 0.0);
   if (!fn) return hipErrorInvalidValue;
+  const BatchLmCont cont{static_cast<BatchLmDynState*>(cont_state), cont_params, cont_frames, cont_done};
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(num_pairs)), dim3(kBlock), 0, stream, pl, desc, io, opt, ticket,
-                     seq_host_dev, seq);
+                     seq_host_dev, seq, cont_state ? sweep_cap : 0, cont);
+  return hipGetLastError();
+}
+
+// After a capped batch_lm_kernel: the pairs it handed over become the first active list (parity 1).
+hipError_t launch_batch_dyn_first_list(BatchDynCtl* ctl, unsigned int* active, const int* done, int num_pairs, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(batch_dyn_identity_kernel, dim3((static_cast<unsigned>(num_pairs) + 255u) / 256u), dim3(256), 0, stream, ctl, active,
+                     num_pairs);
+  hipLaunchKernelGGL(batch_dyn_compact_kernel, dim3(1), dim3(256), 0, stream, ctl, active, done, num_pairs, 0,
+                     static_cast<unsigned long long*>(nullptr), 0ull);
   return hipGetLastError();
 }
 
@@ -669,6 +902,41 @@ hipError_t launch_batch_step(int mode, int depth, int store, int kind, double hu
   else
     hipLaunchKernelGGL(batch_finalize_kernel, dim3(1), dim3(1024), 0, stream, partials, bpp, num_pairs, packs,
                        packs_host, seq);
+  return hipGetLastError();
+}
+
+size_t batch_lm_dyn_state_bytes() { return sizeof(BatchLmDynState); }
+
+hipError_t launch_batch_lm_dyn_init(int mode, int depth, int kind, const PairDesc* desc, const BatchLmIo* io, const sba_lm_options& opt,
+                                    int num_pairs, void* state, SweepParams* params, double* frames, BatchDynCtl* ctl,
+                                    unsigned int* active, int* done, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(batch_lm_dyn_init_kernel, dim3(static_cast<unsigned>(num_pairs)), dim3(64), 0, stream, mode, depth, kind, desc, io, opt,
+                     num_pairs, static_cast<BatchLmDynState*>(state), params, frames, ctl, active, done);
+  return hipGetLastError();
+}
+
+// One LM iteration of every pair that is still iterating: sweep (sweep_grid blocks dealt to the active pairs), feed, compaction.
+// host_words / seq: as batch_dyn_compact_kernel (null: no publication after this iteration).
+hipError_t launch_batch_lm_dyn_pass(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
+                                    const sba_lm_options& opt, int num_pairs, int parity, int sweep_grid, void* state,
+                                    SweepParams* params, double* frames, BatchDynCtl* ctl, unsigned int* active, int* done,
+                                    double* partials, BatchLmIo* io, unsigned long long* host_words, unsigned long long seq,
+                                    hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  BatchDynFn fn = dpick(mode, depth, store, kind, opt.huber_delta > 0.0);
+  if (!fn || sweep_grid < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(sweep_grid)), dim3(kBlock), 0, stream, pl, params, desc, ctl, active, parity, num_pairs,
+                     partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const unsigned feed_grid = static_cast<unsigned>(num_pairs < 1024 ? num_pairs : 1024);
+  hipLaunchKernelGGL(batch_lm_dyn_feed_kernel, dim3(feed_grid), dim3(64), 0, stream, mode, depth, kind, desc, opt, num_pairs, parity,
+                     static_cast<unsigned>(sweep_grid), ctl, active, partials, static_cast<BatchLmDynState*>(state), params, frames, io,
+                     done);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(batch_dyn_compact_kernel, dim3(1), dim3(256), 0, stream, ctl, active, done, num_pairs, parity, host_words, seq);
   return hipGetLastError();
 }
 

@@ -151,10 +151,32 @@ struct BatchLmIo {
 };
 // ticket: one zeroed device word; seq_host_dev (may be null): device-visible address of a host word that receives `seq`
 // once every pair's record has been written.
+// sweep_cap / cont_*: with cont_state != nullptr the kernel runs at most sweep_cap sweeps per pair; a pair that needs more
+// leaves its solver (cont_state[pair], batch_lm_dyn_state_bytes() each), the state of its next sweep (cont_params / cont_frames)
+// and cont_done[pair] = 0 behind, and its record says pad_ = 1; the launches with dynamic shares below take over.
 hipError_t launch_batch_lm(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
                            BatchLmIo* io, const sba_lm_options& opt, int num_pairs, unsigned int* ticket,
-                           unsigned long long* seq_host_dev, unsigned long long seq, hipStream_t stream);
+                           unsigned long long* seq_host_dev, unsigned long long seq, hipStream_t stream, int sweep_cap = 0,
+                           void* cont_state = nullptr, SweepParams* cont_params = nullptr, double* cont_frames = nullptr,
+                           int* cont_done = nullptr);
 hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool loss, int* blocks);
+// Device-resident per-pair solves with DYNAMIC shares (sba_batch_kernels.hip, sba_depth.hip): every iteration / pass is a
+// sweep launch whose blocks are dealt out to the pairs that are still iterating, a per-pair step launch and a compaction
+// launch -- all enqueued without waiting; pairs that have converged hand their CUs to the others.
+struct BatchDynCtl { unsigned int nactive[2]; unsigned int pad_[2]; };
+// shares per active pair of a launch of `grid` blocks (1 when there are at least as many pairs as blocks)
+SBA_HD inline unsigned dyn_shares(unsigned nactive, unsigned grid) { return nactive == 0u || nactive >= grid ? 1u : grid / nactive; }
+size_t batch_lm_dyn_state_bytes();
+hipError_t launch_batch_dyn_first_list(BatchDynCtl* ctl, unsigned int* active, const int* done, int num_pairs, hipStream_t stream);
+hipError_t launch_batch_lm_dyn_init(int mode, int depth, int kind, const PairDesc* desc, const BatchLmIo* io, const sba_lm_options& opt,
+                                    int num_pairs, void* state, SweepParams* params, double* frames, BatchDynCtl* ctl,
+                                    unsigned int* active, int* done, hipStream_t stream);
+hipError_t launch_batch_lm_dyn_pass(int mode, int depth, int store, int kind, const Planes& pl, const PairDesc* desc,
+                                    const sba_lm_options& opt, int num_pairs, int parity, int sweep_grid, void* state,
+                                    SweepParams* params, double* frames, BatchDynCtl* ctl, unsigned int* active, int* done,
+                                    double* partials, BatchLmIo* io, unsigned long long* host_words, unsigned long long seq,
+                                    hipStream_t stream);
+
 hipError_t launch_batch_sweep(int mode, int depth, int store, int kind, bool loss, const Planes& pl,
                               const SweepParams* params, const PairDesc* desc, int num_pairs, int bpp,
                               double* partials, double* packs, double* packs_host, unsigned long long seq,

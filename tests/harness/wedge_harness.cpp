@@ -90,7 +90,7 @@ hipError_t launch_batch_step_fused(int, int, int, int, double, const Planes&, co
   publish(host, static_cast<size_t>(24) * np, seq); return hipSuccess;
 }
 hipError_t launch_batch_lm(int, int, int, int, const Planes&, const PairDesc*, BatchLmIo* io, const sba_lm_options&, int np, unsigned int*,
-                           unsigned long long* seq_host, unsigned long long seq, hipStream_t) {
+                           unsigned long long* seq_host, unsigned long long seq, hipStream_t, int, void*, SweepParams*, double*, int*) {
   if (!g_wedged) { for (int g = 0; g < np; ++g) io[g].status = SBA_OK; if (seq_host) *reinterpret_cast<volatile unsigned long long*>(seq_host) = seq; }
   return hipSuccess;
 }
@@ -126,6 +126,16 @@ hipError_t launch_batch_depth_solve(int, const Planes&, const PairDesc*, const B
                                     double*, double*, double*, double*, double*, double*, const unsigned long long*, double*, BatchLmIo*,
                                     unsigned int*, unsigned long long* seq_host, unsigned long long seq, hipStream_t) {
   publish(reinterpret_cast<double*>(seq_host), 0, seq); return hipSuccess;
+}
+size_t batch_lm_dyn_state_bytes() { return 2048; }
+hipError_t launch_batch_dyn_first_list(BatchDynCtl*, unsigned int*, const int*, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_lm_dyn_init(int, int, int, const PairDesc*, const BatchLmIo*, const sba_lm_options&, int, void*, SweepParams*, double*,
+                                    BatchDynCtl*, unsigned int*, int*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_lm_dyn_pass(int, int, int, int, const Planes&, const PairDesc*, const sba_lm_options&, int, int, int, void*, SweepParams*,
+                                    double*, BatchDynCtl*, unsigned int*, int*, double*, BatchLmIo*, unsigned long long* host_words,
+                                    unsigned long long seq, hipStream_t) {
+  if (host_words && !g_wedged) host_words[0] = 0;          // "no pair is still iterating"
+  publish(reinterpret_cast<double*>(host_words), 1, seq); return hipSuccess;
 }
 hipError_t launch_batch_depth_finish(int, const PairDesc*, const unsigned char*, int, double*, double*, const double*, const double*,
                                      const unsigned long long*, double*, hipStream_t) { return hipSuccess; }

@@ -316,6 +316,60 @@ def test_batch_upload_pipelined_relayout_and_reuse(store, layout, monkeypatch):
             b2.set_depths(D)                                                             # nothing uploaded yet
 
 
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("kind", [api.KERNEL_FACTORED, api.KERNEL_EXPLICIT], ids=["factored", "explicit"])
+def test_batch_lm_dynamic_shares_equals_the_one_launch_solve(oracle, store, kind, monkeypatch):
+    """SBA_BATCH_DYNAMIC=1: per-pair LM as launches per iteration whose blocks are dealt out to the pairs that are still
+    iterating (converged pairs hand their CUs over).  Same LmSolver source, same sweeps: iteration counts and terminations
+    equal the default path's for every pair (here, with fewer pairs than CUs, the host lock-step loop; the C5-sized comparison
+    with the one-launch kernel is tools/batch_pipeline_workload.py), results to 1e-11 (a pair swept by several blocks folds its sums in another
+    order), for every mode / depth mode, pairs that need very different iteration counts (good and poor starts), an empty
+    pair, a 1-match pair, ragged tails; and few long pairs (several blocks per pair from the start)."""
+    sizes = [3000, 0, 1, 257, 5000, 64, 1023, 2] + [400 + 37 * g for g in range(40)]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=7100)
+    B = len(sizes)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    rot0[::3] = np.stack([c.rot_true for c in cs])[::3] + 0.25          # poor starts: many more iterations for a third of the pairs
+    d1 = np.linspace(0.9, 1.4, B); d2 = np.linspace(1.2, 0.8, B)
+    got = {}
+    for dyn in ("0", "1"):
+        monkeypatch.setenv("SBA_BATCH_DYNAMIC", dyn)
+        with api.Batch(0) as b:
+            b.set_kernel(kind)
+            b.upload(x1, x2, off, d12, store=store)
+            got[dyn] = [b.solve(mode, rot0, tran0, d1, d2, depth_mode=dm, options=api.default_lm_options(tran_param=tp))
+                        for mode, dm, tp in ((api.MODE_ROT, api.DEPTH_UNIFORM, api.TRAN_FREE), (api.MODE_TRAN, api.DEPTH_PER_MATCH, api.TRAN_FREE),
+                                             (api.MODE_RT, api.DEPTH_PER_MATCH, api.TRAN_SPHERE))]
+    spread = 0
+    for (r0, t0, s0, st0), (r1, t1, s1, st1) in zip(got["0"], got["1"]):
+        assert np.array_equal(st0, st1) and (st1 == 0).all()
+        assert [(q.num_iterations, q.num_successful_steps, q.termination) for q in s0] == \
+               [(q.num_iterations, q.num_successful_steps, q.termination) for q in s1]
+        assert np.abs(r0 - r1).max() <= 1e-11 and np.abs(t0 - t1).max() <= 1e-11
+        its = [q.num_iterations for q in s1]
+        spread = max(spread, max(its) - min(its))
+    assert spread >= 5                                                    # the shares really changed while the solve ran
+    # few long pairs: several blocks per pair from the first iteration
+    sizes = [120_000, 90_001, 0, 150_000]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=7300)
+    rot0 = np.stack([c.rot_init for c in cs]); tran0 = np.stack([c.tran_init for c in cs])
+    opt = api.default_lm_options(tran_param=api.TRAN_SPHERE)
+    monkeypatch.setenv("SBA_BATCH_DYNAMIC", "1")
+    with api.Batch(0) as b:
+        b.set_kernel(kind)
+        b.upload(x1, x2, off, d12, store=store)
+        rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, depth_mode=api.DEPTH_PER_MATCH, options=opt)
+    assert (status == 0).all()
+    for g, c in enumerate(cs):
+        if sizes[g] == 0:
+            continue
+        with api.Problem(0) as p:
+            p.set_kernel(kind)
+            p.upload(c.x1, c.x2, c.d12, store=store)
+            r1, t1, s1 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH, options=opt)
+        assert sums[g].num_iterations == s1.num_iterations and np.abs(rot[g] - r1).max() <= 1e-10 and np.abs(tran[g] - t1).max() <= 1e-10
+
+
 def test_batch_solve_matches_single_problem_solves(oracle):
     sizes = [4000, 0, 2500, 3333, 1, 5000]
     cs, off, x1, x2, d12 = _make_pairs(sizes)

@@ -45,6 +45,29 @@ with api.Batch(0) as b:
         for k, v in zip(stage, (t1 - t0, t2 - t1, t3 - t2b, t4 - t3, t6 - t5)):
             stage[k].append(v)
         assert np.array_equal(res["rot"], r2) and np.array_equal(res["tran"], tr2)
+    import os
+    dyn = {}
+    for name, flag in (("one_launch", "0"), ("dynamic_shares", "1"), ("hybrid_default", None)):
+        if flag is None:
+            os.environ.pop("SBA_BATCH_DYNAMIC", None)
+        else:
+            os.environ["SBA_BATCH_DYNAMIC"] = flag
+        out = {}
+        for stage, mode, r_in, t_in in (("rot_only", api.MODE_ROT, rot, tran), ("tran_only", api.MODE_TRAN, r1, tr1)):
+            b.solve(mode, r_in, t_in, du1, du2, depth_mode=api.DEPTH_UNIFORM)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rr, tt, ss, _ = b.solve(mode, r_in, t_in, du1, du2, depth_mode=api.DEPTH_UNIFORM)
+                ts.append(time.perf_counter() - t0)
+            out[stage] = (float(np.median(ts)) * 1e3, rr, tt, [q.num_iterations for q in ss])
+        dyn[name] = out
+    os.environ.pop("SBA_BATCH_DYNAMIC", None)
+    for stage in ("rot_only", "tran_only"):
+        assert dyn["one_launch"][stage][3] == dyn["dynamic_shares"][stage][3] == dyn["hybrid_default"][stage][3], "iteration counts differ"
+    print(json.dumps({f"{stage}_{name}_ms": dyn[name][stage][0] for stage in ("rot_only", "tran_only") for name in dyn} |
+                     {"max_abs_difference_to_one_launch": float(max(np.abs(dyn["one_launch"][st][k] - dyn[nm][st][k]).max()
+                                                                   for st in ("rot_only", "tran_only") for nm in ("dynamic_shares", "hybrid_default") for k in (1, 2)))}))
     print(json.dumps({"pairs": B, "matches": n, "reps": reps, **{k + "_ms": float(np.median(v)) * 1e3 for k, v in stage.items()},
                       "d_only_iterations_min_max": [min(q.num_iterations for q in sd), max(q.num_iterations for q in sd)],
                       "d_only_pair_passes": int(sum(q.num_evaluations for q in sd)),
