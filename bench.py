@@ -242,9 +242,12 @@ def run_c5(a):
         # per-pair LM: all pairs solved in lock-step off the batched launches
         opt = api.default_lm_options(tran_param=api.TRAN_SPHERE)
         b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
-        t_lm = time.perf_counter()
-        rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
-        lm_s = time.perf_counter() - t_lm
+        lm_times = []
+        for _ in range(5):          # median: the Python wrapper builds 256 summary objects per call, and one call in a few pays a GC pass
+            t_lm = time.perf_counter()
+            rot, tran, sums, status = b.solve(api.MODE_RT, rot0, tran0, options=opt, **kw)
+            lm_times.append(time.perf_counter() - t_lm)
+        lm_s = float(np.median(lm_times))
         bpp = b.blocks_per_pair
         # the d-only stage of every pair (the first stage of solve_problem, reference .cpp:196-197): one launch, one solver per
         # pair on the device (SBA_BATCH_DEVICE_DEPTH=0: host solvers in lock-step, one launch per pass)

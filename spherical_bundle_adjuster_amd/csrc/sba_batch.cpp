@@ -82,6 +82,8 @@ struct sba_batch {
   unsigned long long* dyn_host = nullptr;    // pinned + mapped: [0] pairs still active, [1] sequence word
   unsigned long long* dyn_host_dev = nullptr;
   unsigned long long dyn_seq = 0;
+  sba::BatchDepthPass* dyn_depth_req = nullptr;   // [num_pairs]: the next pass of every pair of the d-only stage
+  unsigned char* dyn_finish = nullptr;            // [num_pairs]: what batch_depth_finish_kernel has left to do
   // upload: row offsets on the device (relative to the first row), two pinned staging buffers, their DMA-done events
   unsigned long long* offsets_dev = nullptr;
   void* upload_pinned[2] = {nullptr, nullptr};
@@ -117,6 +119,9 @@ int free_batch_data(sba_batch* b) {
   if (b->dyn_state) SBA_TRY_HIP(hipFree(b->dyn_state));
   if (b->dyn_partials) SBA_TRY_HIP(hipFree(b->dyn_partials));
   if (b->dyn_host) SBA_TRY_HIP(hipHostFree(b->dyn_host));
+  if (b->dyn_depth_req) SBA_TRY_HIP(hipFree(b->dyn_depth_req));
+  if (b->dyn_finish) SBA_TRY_HIP(hipFree(b->dyn_finish));
+  b->dyn_depth_req = nullptr; b->dyn_finish = nullptr;
   b->dyn_ctl = nullptr; b->dyn_active = nullptr; b->dyn_done = nullptr; b->dyn_state = nullptr; b->dyn_state_bytes = 0;
   b->dyn_partials = nullptr; b->dyn_partial_rows = 0; b->dyn_host = nullptr; b->dyn_host_dev = nullptr; b->dyn_seq = 0;
   if (b->guess_out_dev) SBA_TRY_HIP(hipFree(b->guess_out_dev));
@@ -724,13 +729,59 @@ int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran,
     for (int g = 0; g < B; ++g) { io[g] = sba::BatchLmIo{}; io[g].status = SBA_ERR_NUMERIC; }
     const unsigned long long seq = ++b->depth_seq;
     unsigned long long* flag_dev = reinterpret_cast<unsigned long long*>(b->depth_out_host_dev + static_cast<size_t>(B) * sba::DEPTH_ROW);
+    // Hybrid (default): the one-launch kernel runs the first passes of every pair and hands the pairs that need more over to
+    // per-pass launches whose blocks are dealt out to the pairs still iterating -- the CUs of the pairs that are done join in.
+    // SBA_BATCH_DEPTH_FIRST_PASSES: the cap of the first launch (default 16; 0: the one-launch kernel runs to the end).
+    int first_passes = 16;
+    if (const char* env = std::getenv("SBA_BATCH_DEPTH_FIRST_PASSES")) { const int v = std::atoi(env); if (v >= 0 && v <= 100000) first_passes = v; }
+    const bool hybrid = first_passes > 0;
+    const int sweep_grid = std::max(1, b->num_cus);
+    if (hybrid) {
+      const int rc2 = ensure_dyn(b, sba::batch_depth_dyn_state_bytes(), static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
+      if (rc2) return rc2;
+      if (!b->dyn_depth_req) {
+        SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_depth_req), sizeof(sba::BatchDepthPass) * B));
+        SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_finish), static_cast<size_t>(B)));
+      }
+      SBA_TRY_HIP(hipMemsetAsync(b->dyn_finish, 0, static_cast<size_t>(B), b->stream));
+    }
     SBA_TRY_HIP(sba::launch_batch_depth_solve(b->store, pl, b->desc_dev, b->depth_const_dev, B, lambda, c, o, b->dplane[0], b->dplane[1],
                                               w1, w2, sc1, sc2, off_dev.as<unsigned long long>(), want_out ? out_dev.as<double>() : nullptr,
-                                              b->lm_io_host_dev, b->lm_ticket, flag_dev, seq, b->stream));
+                                              b->lm_io_host_dev, b->lm_ticket, flag_dev, seq, b->stream, hybrid ? first_passes : 0,
+                                              hybrid ? b->dyn_state : nullptr, b->dyn_depth_req, hybrid ? b->dyn_done : nullptr, b->dyn_finish));
+    int wrc = sba::wait_for_sequence(flag, seq, b->stream, "batched d-only stage", &b->poisoned);
+    if (wrc) return wrc;
+    unsigned long long left = 0;
+    for (int g = 0; g < B; ++g) if (io[g].status == 1) { ++left; io[g].status = SBA_ERR_NUMERIC; }
+    if (left > 0) {
+      SBA_TRY_HIP(sba::launch_batch_dyn_first_list(b->dyn_ctl, b->dyn_active, b->dyn_done, B, b->stream));
+      const int max_passes = sba::batch_depth_pass_bound(o);
+      volatile unsigned long long* words = b->dyn_host;
+      int pass = 0;
+      while (left > 0 && pass < max_passes) {
+        const int group = std::min(4, max_passes - pass);
+        unsigned long long dseq = 0;
+        for (int k = 0; k < group; ++k, ++pass) {
+          const int parity = (1 + pass) & 1;
+          const bool last = k == group - 1;
+          if (last) dseq = ++b->dyn_seq;
+          SBA_TRY_HIP(sba::launch_batch_depth_dyn_pass(b->store, pl, b->desc_dev, b->depth_const_dev, B, lambda, c, o, b->dplane[0], b->dplane[1],
+                                                       w1, w2, sc1, sc2, parity, sweep_grid, b->dyn_state, b->dyn_depth_req, b->dyn_ctl,
+                                                       b->dyn_active, b->dyn_done, b->dyn_finish, b->dyn_partials, b->lm_io_host_dev, b->stream));
+          SBA_TRY_HIP(sba::launch_batch_dyn_compact(b->dyn_ctl, b->dyn_active, b->dyn_done, B, parity, last ? b->dyn_host_dev : nullptr, dseq,
+                                                    b->stream));
+        }
+        wrc = sba::wait_for_sequence(words + 1, dseq, b->stream, "batched d-only stage (dynamic shares)", &b->poisoned);
+        if (wrc) return wrc;
+        left = words[0];
+      }
+      // the pairs that went through the dynamic passes: copy-back and output (bits of dyn_finish)
+      SBA_TRY_HIP(sba::launch_batch_depth_finish(b->store, b->desc_dev, b->dyn_finish, B, b->dplane[0], b->dplane[1], w1, w2,
+                                                 off_dev.as<unsigned long long>(), want_out ? out_dev.as<double>() : nullptr, b->stream));
+    }
     if (want_out)
       SBA_TRY_HIP(hipMemcpyAsync(d12_out + 2 * base, out_dev.ptr, 2 * total * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    int wrc = want_out ? sba::stream_wait(b->stream, "batched d-only stage", &b->poisoned)
-                       : sba::wait_for_sequence(flag, seq, b->stream, "batched d-only stage", &b->poisoned);
+    wrc = sba::stream_wait(b->stream, "batched d-only stage", &b->poisoned);
     if (wrc) return wrc;
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     int failures = 0;
@@ -770,6 +821,7 @@ int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran,
     }
   }
   // results back into the batch's own depth planes (pairs that ended on an odd number of accepted steps), and out to the host
+  for (unsigned char& f : flip) f = static_cast<unsigned char>((f & 1) | 2);      // bit 0: copy back; bit 1: write `out`
   SBA_TRY_HIP(flip_dev.alloc(static_cast<size_t>(B)));
   SBA_TRY_HIP(hipMemcpyAsync(flip_dev.ptr, flip.data(), static_cast<size_t>(B), hipMemcpyHostToDevice, b->stream));
   SBA_TRY_HIP(sba::launch_batch_depth_finish(b->store, b->desc_dev, flip_dev.as<unsigned char>(), B, b->dplane[0], b->dplane[1], w1, w2,

@@ -905,6 +905,13 @@ hipError_t launch_batch_step(int mode, int depth, int store, int kind, double hu
   return hipGetLastError();
 }
 
+hipError_t launch_batch_dyn_compact(BatchDynCtl* ctl, unsigned int* active, const int* done, int num_pairs, int parity,
+                                    unsigned long long* host_words, unsigned long long seq, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(batch_dyn_compact_kernel, dim3(1), dim3(256), 0, stream, ctl, active, done, num_pairs, parity, host_words, seq);
+  return hipGetLastError();
+}
+
 size_t batch_lm_dyn_state_bytes() { return sizeof(BatchLmDynState); }
 
 hipError_t launch_batch_lm_dyn_init(int mode, int depth, int kind, const PairDesc* desc, const BatchLmIo* io, const sba_lm_options& opt,

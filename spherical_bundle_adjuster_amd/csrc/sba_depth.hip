@@ -328,6 +328,21 @@ __global__ __launch_bounds__(512, 2) void batch_depth_step_kernel(Planes pl, con
   }
 }
 
+// Per-pair state of the d-only stage that outlives a launch (device memory): with a pass cap the one-launch kernel below hands
+// a pair that is not done within its first passes over to the launches with dynamic shares (batch_depth_dyn_kernel ...).
+struct BatchDepthDynState {
+  DepthStageSolver solver;
+  int flip;                 // the pair's current depths are in the work planes
+  int passes;
+};
+static_assert(sizeof(DepthStageSolver) % 8 == 0 && sizeof(BatchDepthDynState) % 8 == 0, "copied as 8-byte words");
+struct BatchDepthCont {     // all null: the kernel runs every pair to the end
+  BatchDepthDynState* state;
+  BatchDepthPass* req;      // the pair's next pass (flags: bit 0 first, bit 1 keep diagonal, bit 3 flip)
+  int* done;
+  unsigned char* finish;    // what batch_depth_finish_kernel still has to do for the pair: bit 0 copy back, bit 1 write `out`
+};
+
 // The whole d-only stage of a pair in ONE launch: the block that owns the pair keeps the pair's DepthStageSolver (the very
 // class the host drives -- sba_depth_solver.hpp and sba_line_search.hpp are __host__ __device__) in LDS, thread 0 feeds it the
 // nine reductions of the pass just run and takes the next request from it, the block runs that pass.  No host round trip
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, co
                                                                   double* __restrict__ out, BatchLmIo* __restrict__ io,
                                                                   unsigned int* __restrict__ ticket,
                                                                   unsigned long long* __restrict__ seq_host, unsigned long long seq,
-                                                                  int max_trips) {
+                                                                  int max_trips, BatchDepthCont cont) {
   __shared__ double red[8][DEPTH_OUT_COUNT];
   __shared__ double res_s[DEPTH_ROW];
   __shared__ double req_s[2];                 // radius, alpha of the next pass
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, co
     flip_s = 0;
     passes_s = 0;
   }
-  for (int trip = 0; trip < max_trips; ++trip) {
+  for (int trip = 0; trip <= max_trips; ++trip) {      // the trip after the last pass only feeds its reductions (and breaks below)
     __syncthreads();                        // B0: the previous pass's reductions are in res_s
     if (tid == 0) {
       if (trip > 0) {
@@ -387,11 +402,11 @@ __global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, co
         const DepthPassRequest& rq = solver->request();
         req_s[0] = rq.radius; req_s[1] = rq.alpha;
         flags_s = (rq.first ? 1 : 0) | (rq.keep_diagonal ? 2 : 0) | (flip_s ? 8 : 0);
-        ++passes_s;
+        if (trip < max_trips) ++passes_s;
       }
     }
     __syncthreads();                        // B1: done_s / the next pass are visible to the block
-    if (done_s) break;
+    if (done_s || trip == max_trips) break; // both block-uniform: an LDS word read after B1, the trip counter
     const int fl = flags_s;
     P.radius = req_s[0]; P.inv_radius = 1.0 / P.radius; P.alpha = req_s[1];
     P.first_iteration = fl & 1; P.reuse_diagonal = (fl >> 1) & 1;
@@ -403,7 +418,8 @@ __global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, co
     if (tid < DEPTH_OUT_COUNT) res_s[tid] = s;
   }
   __syncthreads();                          // flip_s is final; every store of the last pass has been issued by its thread
-  {
+  const bool handed_over = !done_s && cont.state != nullptr;      // the pass cap ended the loop: the pair goes on in the dynamic launches
+  if (!handed_over) {
     const bool fl = flip_s != 0;            // as batch_depth_finish_kernel, for this block's own pair
     const size_t npairs = (dsc.n + 1) / 2;
     if (fl || out)
@@ -419,9 +435,18 @@ __global__ __launch_bounds__(512, 2) void batch_depth_solve_kernel(Planes pl, co
       }
   }
   if (tid == 0) {
+    if (handed_over) {
+      BatchDepthDynState* st = cont.state + pair;
+      for (unsigned k = 0; k < sizeof(DepthStageSolver) / 8; ++k)
+        reinterpret_cast<double*>(&st->solver)[k] = reinterpret_cast<const double*>(solver_mem)[k];
+      st->flip = flip_s; st->passes = passes_s + 1;      // passes whose request has been issued: the pending one counts
+      cont.req[pair] = BatchDepthPass{req_s[0], req_s[1], dsc.n, static_cast<unsigned>(flags_s), 0u};
+    }
+    if (cont.done) cont.done[pair] = handed_over ? 0 : 1;
+    if (cont.finish) cont.finish[pair] = 0;            // a pair that ends here has done its own copy-back and output above
     BatchLmIo res{};
     res.summary = solver->summary();
-    res.status = solver->done() ? solver->status() : SBA_ERR_NUMERIC;   // the trip bound ran out: cannot happen, but never silent
+    res.status = handed_over ? 1 : (solver->done() ? solver->status() : SBA_ERR_NUMERIC);   // 1: continues; else the bound ran out: never silent
     res.pad_ = passes_s;
     // init_d[0][0] and init_d[1][0] of the pair: what the reference's rot / tran stages use as the depths of EVERY match
     // (.cpp:941-942, :998-999).  Thread 0 stored both itself (its lane handles the pair's first two matches).
@@ -452,7 +477,9 @@ __global__ __launch_bounds__(256) void batch_depth_finish_kernel(const PairDesc*
   const unsigned pair = blockIdx.x;
   const PairDesc dsc = desc[pair];
   const BatchPairMap<ST> map{dsc};
-  const bool fl = flip[pair] != 0;
+  const bool fl = (flip[pair] & 1) != 0;       // bit 0: copy back; bit 1: write `out` (a pair with neither is already complete)
+  if (!(flip[pair] & 2)) out = nullptr;
+  if (!fl && !out) return;
   const size_t npairs = (dsc.n + 1) / 2;
   for (size_t pr = threadIdx.x; pr < npairs; pr += 256) {
     const size_t q = map(pr);
@@ -463,6 +490,110 @@ __global__ __launch_bounds__(256) void batch_depth_finish_kernel(const PairDesc*
       reinterpret_cast<double2*>(out)[i] = make_double2(u.x, v.x);
       if (2 * pr + 1 < dsc.n) reinterpret_cast<double2*>(out)[i + 1] = make_double2(u.y, v.y);
     }
+  }
+}
+
+// ---- the tail of the batched d-only stage with DYNAMIC shares (sba_device.hpp: BatchDynCtl) ---------------------------------------
+// Per pass three launches, enqueued without waiting: batch_depth_dyn_kernel (the launch's blocks dealt out to the pairs that
+// are still iterating: share j of S runs the pair's pass over vectors j * 512 + tid + k * 512 * S and leaves its nine
+// reductions in partials[(slot * S + j) * 16]), batch_depth_dyn_feed_kernel (one wave per active pair: fold the rows in share
+// order, feed the pair's DepthStageSolver -- in LDS for the step --, next request or result) and the compaction of the
+// active list (batch_dyn_compact_kernel).
+template <typename ST>
+__global__ __launch_bounds__(512, 2) void batch_depth_dyn_kernel(Planes pl, const PairDesc* __restrict__ desc,
+                                                                const BatchDepthConst* __restrict__ cst, const BatchDepthPass* __restrict__ req,
+                                                                double lambda, double c, double min_diagonal, double max_diagonal,
+                                                                int jacobi_scaling, double* __restrict__ a1, double* __restrict__ a2,
+                                                                double* __restrict__ b1, double* __restrict__ b2, double* __restrict__ sc1,
+                                                                double* __restrict__ sc2, const BatchDynCtl* __restrict__ ctl,
+                                                                const unsigned int* __restrict__ active, int parity, int num_pairs,
+                                                                double* __restrict__ partials) {
+  __shared__ double red[8][DEPTH_OUT_COUNT];
+  const int tid = threadIdx.x;
+  const unsigned na = ctl->nactive[parity], G = gridDim.x;
+  const unsigned S = dyn_shares(na, G);
+  for (unsigned item = blockIdx.x; item < na * S; item += G) {
+    const unsigned slot = item / S, j = item - slot * S;
+    const unsigned pair = active[static_cast<size_t>(parity) * num_pairs + slot];
+    const PairDesc dsc = desc[pair];
+    const BatchDepthPass ps = req[pair];
+    DepthParams P;
+    {
+      const BatchDepthConst k = cst[pair];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) P.R[i] = k.R[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) P.t[i] = k.t[i];
+    }
+    P.lambda = lambda; P.c = c; P.radius = ps.radius; P.inv_radius = 1.0 / ps.radius;
+    P.min_diagonal = min_diagonal; P.max_diagonal = max_diagonal; P.alpha = ps.alpha;
+    P.first_iteration = ps.flags & 1; P.reuse_diagonal = (ps.flags >> 1) & 1; P.jacobi_scaling = jacobi_scaling;
+    P.stream_stores = 0; P.n = dsc.n;
+    const bool flip = (ps.flags >> 3) & 1;
+    double r[DEPTH_OUT_COUNT];
+    depth_stream<ST, 1, BatchPairMap<ST>>(pl, flip ? b1 : a1, flip ? b2 : a2, flip ? a1 : b1, flip ? a2 : b2, sc1, sc2, P,
+                                          static_cast<size_t>(j) * 512 + tid, static_cast<size_t>(S) * 512, r, BatchPairMap<ST>{dsc});
+    const double s = depth_block_fold<8>(r, red);
+    if (tid < DEPTH_OUT_COUNT) partials[static_cast<size_t>(item) * DEPTH_ROW + tid] = s;
+    __syncthreads();                                  // `red` is reused by the next item
+  }
+}
+
+template <typename ST>
+__global__ __launch_bounds__(64) void batch_depth_dyn_feed_kernel(const PairDesc* __restrict__ desc, int num_pairs, int parity,
+                                                                 unsigned sweep_grid, const BatchDynCtl* __restrict__ ctl,
+                                                                 const unsigned int* __restrict__ active,
+                                                                 const double* __restrict__ partials, BatchDepthDynState* __restrict__ state,
+                                                                 BatchDepthPass* __restrict__ req, const double* __restrict__ a1,
+                                                                 const double* __restrict__ b1, BatchLmIo* __restrict__ io,
+                                                                 int* __restrict__ done, unsigned char* __restrict__ finish) {
+  __shared__ alignas(16) unsigned char mem[sizeof(BatchDepthDynState)];
+  __shared__ double res_s[DEPTH_ROW];
+  BatchDepthDynState* st = reinterpret_cast<BatchDepthDynState*>(mem);
+  const int lane = threadIdx.x;
+  const unsigned na = ctl->nactive[parity];
+  const unsigned S = dyn_shares(na, sweep_grid);
+  for (unsigned slot = blockIdx.x; slot < na; slot += gridDim.x) {
+    const unsigned pair = active[static_cast<size_t>(parity) * num_pairs + slot];
+    for (unsigned k = lane; k < sizeof(BatchDepthDynState) / 8; k += 64)
+      reinterpret_cast<double*>(mem)[k] = reinterpret_cast<const double*>(state + pair)[k];
+    if (lane < DEPTH_OUT_COUNT) {                     // the pair's share rows, in share order: seven sums, two maxima
+      const double* rows = partials + static_cast<size_t>(slot) * S * DEPTH_ROW + lane;
+      double v = rows[0];
+      for (unsigned j = 1; j < S; ++j) {
+        const double w = rows[static_cast<size_t>(j) * DEPTH_ROW];
+        v = lane < DEPTH_OUT_SUMS ? v + w : fmax(v, w);
+      }
+      res_s[lane] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      st->solver.feed(res_s);
+      if (st->solver.take_candidate()) st->flip ^= 1;
+      if (st->solver.done()) {
+        const PairDesc dsc = desc[pair];
+        BatchLmIo res{};
+        res.summary = st->solver.summary();
+        res.status = st->solver.status();
+        res.pad_ = st->passes;
+        if (dsc.n > 0) {
+          const double2 u0 = reinterpret_cast<const double2*>(st->flip ? b1 : a1)[BatchPairMap<ST>{dsc}(0)];
+          res.d1 = u0.x; res.d2 = dsc.n > 1 ? u0.y : u0.x;
+        }
+        io[pair] = res;                               // mapped host memory; read by the host after the last publication
+        finish[pair] = static_cast<unsigned char>((st->flip ? 1 : 0) | 2);
+        done[pair] = 1;
+      } else {
+        const DepthPassRequest& rq = st->solver.request();
+        req[pair] = BatchDepthPass{rq.radius, rq.alpha, 0ull,
+                                   static_cast<unsigned>((rq.first ? 1 : 0) | (rq.keep_diagonal ? 2 : 0) | (st->flip ? 8 : 0)), 0u};
+        st->passes += 1;
+      }
+    }
+    __syncthreads();
+    for (unsigned k = lane; k < sizeof(BatchDepthDynState) / 8; k += 64)
+      reinterpret_cast<double*>(state + pair)[k] = reinterpret_cast<const double*>(mem)[k];
+    __syncthreads();                                  // mem / res_s are reused by the next slot
   }
 }
 
@@ -562,21 +693,47 @@ hipError_t launch_batch_depth_solve(int store, const Planes& pl, const PairDesc*
                                     double lambda, double c, const sba_lm_options& opt, double* a1, double* a2, double* b1, double* b2,
                                     double* sc1, double* sc2, const unsigned long long* offsets_dev, double* out_dev, BatchLmIo* io,
                                     unsigned int* ticket, unsigned long long* seq_host_dev, unsigned long long seq,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, int pass_cap, void* cont_state, BatchDepthPass* cont_req, int* cont_done,
+                                    unsigned char* cont_finish) {
   if (num_pairs <= 0) return hipSuccess;
-  // passes a pair can need: per iteration the trust-region pass, up to max_num_line_search_step_size_iterations
-  // contractions and one pass that restores the full step; one more pass detects the iteration limit
-  const long long its = opt.max_num_iterations > 0 ? opt.max_num_iterations : 0;
-  const long long lsn = opt.max_num_line_search_step_size_iterations > 0 ? opt.max_num_line_search_step_size_iterations : 0;
-  long long bound = its * (lsn + 2) + 4;
-  if (bound > (1ll << 24)) bound = 1ll << 24;
-  const int max_trips = static_cast<int>(bound);
+  int max_trips = batch_depth_pass_bound(opt);
+  if (cont_state && pass_cap > 0 && pass_cap < max_trips) max_trips = pass_cap;
+  const BatchDepthCont cont{static_cast<BatchDepthDynState*>(cont_state), cont_req, cont_done, cont_finish};
   if (store == 0)
     hipLaunchKernelGGL((batch_depth_solve_kernel<double>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, lambda, c, opt, a1, a2,
-                       b1, b2, sc1, sc2, offsets_dev, out_dev, io, ticket, seq_host_dev, seq, max_trips);
+                       b1, b2, sc1, sc2, offsets_dev, out_dev, io, ticket, seq_host_dev, seq, max_trips, cont);
   else
     hipLaunchKernelGGL((batch_depth_solve_kernel<float>), dim3(num_pairs), dim3(512), 0, stream, pl, desc, cst, lambda, c, opt, a1, a2,
-                       b1, b2, sc1, sc2, offsets_dev, out_dev, io, ticket, seq_host_dev, seq, max_trips);
+                       b1, b2, sc1, sc2, offsets_dev, out_dev, io, ticket, seq_host_dev, seq, max_trips, cont);
+  return hipGetLastError();
+}
+
+size_t batch_depth_dyn_state_bytes() { return sizeof(BatchDepthDynState); }
+
+// One pass of every pair that is still iterating (sweep + feed; the caller adds the compaction launch).
+hipError_t launch_batch_depth_dyn_pass(int store, const Planes& pl, const PairDesc* desc, const BatchDepthConst* cst, int num_pairs,
+                                       double lambda, double c, const sba_lm_options& opt, double* a1, double* a2, double* b1, double* b2,
+                                       double* sc1, double* sc2, int parity, int sweep_grid, void* state, BatchDepthPass* req,
+                                       const BatchDynCtl* ctl, const unsigned int* active, int* done, unsigned char* finish,
+                                       double* partials, BatchLmIo* io, hipStream_t stream) {
+  if (num_pairs <= 0) return hipSuccess;
+  if (sweep_grid < 1) return hipErrorInvalidValue;
+  const unsigned feed_grid = static_cast<unsigned>(num_pairs < 1024 ? num_pairs : 1024);
+  if (store == 0) {
+    hipLaunchKernelGGL((batch_depth_dyn_kernel<double>), dim3(static_cast<unsigned>(sweep_grid)), dim3(512), 0, stream, pl, desc, cst, req, lambda,
+                       c, opt.min_lm_diagonal, opt.max_lm_diagonal, opt.jacobi_scaling ? 1 : 0, a1, a2, b1, b2, sc1, sc2, ctl, active, parity,
+                       num_pairs, partials);
+    hipLaunchKernelGGL((batch_depth_dyn_feed_kernel<double>), dim3(feed_grid), dim3(64), 0, stream, desc, num_pairs, parity,
+                       static_cast<unsigned>(sweep_grid), ctl, active, partials, static_cast<BatchDepthDynState*>(state), req, a1, b1, io, done,
+                       finish);
+  } else {
+    hipLaunchKernelGGL((batch_depth_dyn_kernel<float>), dim3(static_cast<unsigned>(sweep_grid)), dim3(512), 0, stream, pl, desc, cst, req, lambda,
+                       c, opt.min_lm_diagonal, opt.max_lm_diagonal, opt.jacobi_scaling ? 1 : 0, a1, a2, b1, b2, sc1, sc2, ctl, active, parity,
+                       num_pairs, partials);
+    hipLaunchKernelGGL((batch_depth_dyn_feed_kernel<float>), dim3(feed_grid), dim3(64), 0, stream, desc, num_pairs, parity,
+                       static_cast<unsigned>(sweep_grid), ctl, active, partials, static_cast<BatchDepthDynState*>(state), req, a1, b1, io, done,
+                       finish);
+  }
   return hipGetLastError();
 }
 

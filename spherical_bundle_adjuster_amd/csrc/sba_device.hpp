@@ -256,7 +256,29 @@ hipError_t launch_batch_depth_solve(int store, const Planes& pl, const PairDesc*
                                     double lambda, double c, const sba_lm_options& opt, double* a1, double* a2, double* b1, double* b2,
                                     double* sc1, double* sc2, const unsigned long long* offsets_dev, double* out_dev, BatchLmIo* io,
                                     unsigned int* ticket, unsigned long long* seq_host_dev, unsigned long long seq,
-                                    hipStream_t stream);
+                                    hipStream_t stream, int pass_cap = 0, void* cont_state = nullptr, BatchDepthPass* cont_req = nullptr,
+                                    int* cont_done = nullptr, unsigned char* cont_finish = nullptr);
+// passes a pair can need: per iteration the trust-region pass, up to max_num_line_search_step_size_iterations contractions and
+// one pass that restores the full step; a few more detect the iteration limit
+inline int batch_depth_pass_bound(const sba_lm_options& opt) {
+  const long long its = opt.max_num_iterations > 0 ? opt.max_num_iterations : 0;
+  const long long lsn = opt.max_num_line_search_step_size_iterations > 0 ? opt.max_num_line_search_step_size_iterations : 0;
+  long long bound = its * (lsn + 2) + 4;
+  if (bound > (1ll << 24)) bound = 1ll << 24;
+  return static_cast<int>(bound);
+}
+// With cont_state != nullptr (batch_depth_dyn_state_bytes() per pair) the kernel runs at most pass_cap passes per pair; a pair
+// that needs more leaves its solver and next request behind (record.status == 1, cont_done[pair] = 0) for the passes with
+// dynamic shares: launch_batch_depth_dyn_pass + launch_batch_dyn_compact per pass.  cont_finish[pair] tells
+// launch_batch_depth_finish what is left to do for the pair (bit 0 copy back, bit 1 write out).
+size_t batch_depth_dyn_state_bytes();
+hipError_t launch_batch_depth_dyn_pass(int store, const Planes& pl, const PairDesc* desc, const BatchDepthConst* cst, int num_pairs,
+                                       double lambda, double c, const sba_lm_options& opt, double* a1, double* a2, double* b1, double* b2,
+                                       double* sc1, double* sc2, int parity, int sweep_grid, void* state, BatchDepthPass* req,
+                                       const BatchDynCtl* ctl, const unsigned int* active, int* done, unsigned char* finish,
+                                       double* partials, BatchLmIo* io, hipStream_t stream);
+hipError_t launch_batch_dyn_compact(BatchDynCtl* ctl, unsigned int* active, const int* done, int num_pairs, int parity,
+                                    unsigned long long* host_words, unsigned long long seq, hipStream_t stream);
 hipError_t launch_batch_depth_finish(int store, const PairDesc* desc, const unsigned char* flip_dev, int num_pairs, double* a1,
                                      double* a2, const double* b1, const double* b2, const unsigned long long* offsets_dev,
                                      double* out_dev, hipStream_t stream);

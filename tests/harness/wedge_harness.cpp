@@ -124,8 +124,18 @@ hipError_t launch_batch_depth_step(int, const Planes&, const PairDesc*, const Ba
 }
 hipError_t launch_batch_depth_solve(int, const Planes&, const PairDesc*, const BatchDepthConst*, int, double, double, const sba_lm_options&,
                                     double*, double*, double*, double*, double*, double*, const unsigned long long*, double*, BatchLmIo*,
-                                    unsigned int*, unsigned long long* seq_host, unsigned long long seq, hipStream_t) {
+                                    unsigned int*, unsigned long long* seq_host, unsigned long long seq, hipStream_t, int, void*, BatchDepthPass*,
+                                    int*, unsigned char*) {
   publish(reinterpret_cast<double*>(seq_host), 0, seq); return hipSuccess;
+}
+size_t batch_depth_dyn_state_bytes() { return 1024; }
+hipError_t launch_batch_depth_dyn_pass(int, const Planes&, const PairDesc*, const BatchDepthConst*, int, double, double, const sba_lm_options&,
+                                       double*, double*, double*, double*, double*, double*, int, int, void*, BatchDepthPass*, const BatchDynCtl*,
+                                       const unsigned int*, int*, unsigned char*, double*, BatchLmIo*, hipStream_t) { return hipSuccess; }
+hipError_t launch_batch_dyn_compact(BatchDynCtl*, unsigned int*, const int*, int, int, unsigned long long* host_words, unsigned long long seq,
+                                    hipStream_t) {
+  if (host_words && !g_wedged) host_words[0] = 0;
+  publish(reinterpret_cast<double*>(host_words), 1, seq); return hipSuccess;
 }
 size_t batch_lm_dyn_state_bytes() { return 2048; }
 hipError_t launch_batch_dyn_first_list(BatchDynCtl*, unsigned int*, const int*, int, hipStream_t) { return hipSuccess; }

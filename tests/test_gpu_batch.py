@@ -134,6 +134,7 @@ def test_batch_depth_stage_one_launch_equals_lock_step_bitwise(monkeypatch):
     cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=11)
     rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
     start = np.full_like(d12, 1.5)
+    monkeypatch.setenv("SBA_BATCH_DEPTH_FIRST_PASSES", "0")        # the one-launch kernel to the end: same reduction order as the host path
     for opts in (None, api.default_lm_options(max_num_line_search_step_size_iterations=0), api.default_lm_options(max_num_iterations=3)):
         got = {}
         for driver in ("1", "0"):
@@ -149,6 +150,38 @@ def test_batch_depth_stage_one_launch_equals_lock_step_bitwise(monkeypatch):
             assert (a.num_iterations, a.num_successful_steps, a.num_line_search_steps, a.num_evaluations, a.termination, a.final_cost,
                     a.final_radius) == (h.num_iterations, h.num_successful_steps, h.num_line_search_steps, h.num_evaluations,
                                         h.termination, h.final_cost, h.final_radius)
+
+
+@pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("first", ["1", "3", "7"])
+def test_batch_depth_stage_hand_over_to_dynamic_shares(store, first, monkeypatch):
+    """Default driver of sba_batch_solve_depths: the one-launch kernel runs the first passes of every pair, pairs that need more
+    are handed over -- solver state, current / candidate planes, Jacobi scaling -- to per-pass launches whose blocks are dealt
+    out to the pairs still iterating.  Whatever the hand-over point (1, 3, 7 passes: before, inside and after line searches),
+    every pair must take exactly the passes, iterations and contractions of the one-launch kernel and end at its depths
+    (1e-8: a pair swept by several blocks folds its nine reductions in another order); pairs that finish inside the first
+    launch, an empty and a 1-match pair, a following stage starting from the refined depths."""
+    sizes = [3000, 1, 0, 777, 4096, 50, 20000] + [900 + 31 * g for g in range(30)]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=11)
+    rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
+    start = np.full_like(d12, 1.5)
+    start[off[3]:off[4]] = d12[off[3]:off[4]]                        # one pair starts at the answer: done within the first launch
+    got = {}
+    for cap in ("0", first):
+        monkeypatch.setenv("SBA_BATCH_DEPTH_FIRST_PASSES", cap)
+        with api.Batch(0) as b:
+            b.upload(x1, x2, off, start, store=store)
+            d, sums, status = b.solve_depths(rot, tran)
+            packs = b.eval(api.MODE_RT, rot, tran, depth_mode=api.DEPTH_PER_MATCH)     # the batch's planes hold the refined depths
+            got[cap] = (d, sums, status, packs)
+    d0, s0, st0, p0 = got["0"]
+    d1, s1, st1, p1 = got[first]
+    assert (st0 == 0).all() and (st1 == 0).all()
+    assert [(q.num_iterations, q.num_successful_steps, q.num_line_search_steps, q.num_evaluations, q.termination) for q in s0] == \
+           [(q.num_iterations, q.num_successful_steps, q.num_line_search_steps, q.num_evaluations, q.termination) for q in s1]
+    assert np.abs(d0 - d1).max() <= 1e-8 * max(1.0, np.abs(d0).max())
+    assert np.abs(p0 - p1).max() <= 1e-8 * np.abs(p0).max()
+    assert max(q.num_evaluations for q in s1) > int(first) + 2          # pairs really went on after the hand-over
 
 
 @pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])

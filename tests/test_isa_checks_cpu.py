@@ -150,12 +150,13 @@ def test_depth_solve_kernels_barriers_are_block_uniform(depth_asm):
     of batch_lm_kernel: B0, B1 and the fold's barrier at loop depth 1 -- the solver's own loops (line-search bisection)
     sit in the thread-0 region and hold no barrier -- and one barrier after the loop at depth 0."""
     funcs = _functions(depth_asm)
-    for pat, count in (("batch_depth_solve_kernel", 2), ("resident_depth_kernel", 2)):
+    for pat, count, want in (("batch_depth_solve_kernel", 2, [0, 1, 1, 1]), ("resident_depth_kernel", 2, [0, 1, 1, 1]),
+                             ("batch_depth_dyn_kernel", 2, [1, 1])):       # the dynamic-share pass: fold + end-of-item barrier per item
         ks = {k: v for k, v in funcs.items() if pat in k}
         assert len(ks) == count, (pat, sorted(ks))
         for name, body in ks.items():
             d = sorted(_barrier_depths(body))
-            assert d == [0, 1, 1, 1], (name, d)
+            assert d == want, (name, d)
 
 
 def test_depth_solve_kernel_keeps_the_stream_out_of_scratch(depth_asm):
