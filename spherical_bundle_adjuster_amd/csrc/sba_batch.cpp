@@ -76,7 +76,6 @@ struct sba_batch {
   unsigned int* dyn_active = nullptr;        // [2][num_pairs]
   int* dyn_done = nullptr;                   // [num_pairs]
   void* dyn_state = nullptr;                 // per-pair solver state
-  size_t dyn_state_bytes = 0;
   double* dyn_partials = nullptr;            // share rows of one launch
   size_t dyn_partial_rows = 0;
   unsigned long long* dyn_host = nullptr;    // pinned + mapped: [0] pairs still active, [1] sequence word
@@ -113,16 +112,8 @@ int free_batch_data(sba_batch* b) {
   if (b->epi_groups_host) SBA_TRY_HIP(hipHostFree(b->epi_groups_host));
   if (b->offsets_dev) SBA_TRY_HIP(hipFree(b->offsets_dev));
   b->offsets_dev = nullptr;
-  if (b->dyn_ctl) SBA_TRY_HIP(hipFree(b->dyn_ctl));
-  if (b->dyn_active) SBA_TRY_HIP(hipFree(b->dyn_active));
-  if (b->dyn_done) SBA_TRY_HIP(hipFree(b->dyn_done));
-  if (b->dyn_state) SBA_TRY_HIP(hipFree(b->dyn_state));
-  if (b->dyn_partials) SBA_TRY_HIP(hipFree(b->dyn_partials));
-  if (b->dyn_host) SBA_TRY_HIP(hipHostFree(b->dyn_host));
-  if (b->dyn_depth_req) SBA_TRY_HIP(hipFree(b->dyn_depth_req));
-  if (b->dyn_finish) SBA_TRY_HIP(hipFree(b->dyn_finish));
-  b->dyn_depth_req = nullptr; b->dyn_finish = nullptr;
-  b->dyn_ctl = nullptr; b->dyn_active = nullptr; b->dyn_done = nullptr; b->dyn_state = nullptr; b->dyn_state_bytes = 0;
+  if (b->dyn_ctl) SBA_TRY_HIP(hipFree(b->dyn_ctl));       // one allocation: everything below is carved from it
+  b->dyn_ctl = nullptr; b->dyn_active = nullptr; b->dyn_done = nullptr; b->dyn_state = nullptr; b->dyn_depth_req = nullptr; b->dyn_finish = nullptr;
   b->dyn_partials = nullptr; b->dyn_partial_rows = 0; b->dyn_host = nullptr; b->dyn_host_dev = nullptr; b->dyn_seq = 0;
   if (b->guess_out_dev) SBA_TRY_HIP(hipFree(b->guess_out_dev));
   if (b->guess_out_host) SBA_TRY_HIP(hipHostFree(b->guess_out_host));
@@ -254,31 +245,35 @@ class PairWorkers {
   std::atomic<bool> quit_{false};
 };
 
-// Buffers of the device-resident solves with dynamic shares; state_bytes: per-pair solver state of the stage that asks.
-int ensure_dyn(sba_batch* b, size_t state_bytes, size_t partial_rows) {
+// Buffers of the device-resident solves with dynamic shares: ONE device allocation, carved (control words, the two active lists,
+// done flags, finish flags, the d-only stage's requests, per-pair solver state sized for the larger of the two solvers, the share
+// rows of one launch); the two host words the compaction kernel publishes to are the spare words behind the packs' sequence word
+// (no further mapped allocation: the first solve of a fresh batch pays one hipMalloc).  max_rows: share rows of one launch.
+int ensure_dyn(sba_batch* b, size_t max_rows) {
   const size_t B = static_cast<size_t>(b->num_pairs);
-  if (!b->dyn_ctl) {
-    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_ctl), sizeof(sba::BatchDynCtl)));
-    SBA_TRY_HIP(hipMemsetAsync(b->dyn_ctl, 0, sizeof(sba::BatchDynCtl), b->stream));      // stream-ordered: never a blocking call here
-    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_active), sizeof(unsigned int) * 2 * B));
-    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_done), sizeof(int) * B));
-    SBA_TRY_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->dyn_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(b->dyn_host, 0, 64);
-    SBA_TRY_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->dyn_host_dev), b->dyn_host, 0));
-    b->dyn_seq = 0;
-  }
-  if (b->dyn_state_bytes < state_bytes * B) {
-    if (b->dyn_state) SBA_TRY_HIP(hipFree(b->dyn_state));
-    b->dyn_state = nullptr; b->dyn_state_bytes = 0;
-    SBA_TRY_HIP(hipMalloc(&b->dyn_state, state_bytes * B));
-    b->dyn_state_bytes = state_bytes * B;
-  }
-  if (b->dyn_partial_rows < partial_rows) {
-    if (b->dyn_partials) SBA_TRY_HIP(hipFree(b->dyn_partials));
-    b->dyn_partials = nullptr; b->dyn_partial_rows = 0;
-    SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_partials), partial_rows * sba::kRow * sizeof(double)));
-    b->dyn_partial_rows = partial_rows;
-  }
+  if (b->dyn_ctl && b->dyn_partial_rows >= max_rows) return SBA_OK;
+  if (b->dyn_ctl) SBA_TRY_HIP(hipFree(b->dyn_ctl));
+  b->dyn_ctl = nullptr;
+  auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t state_each = std::max(sba::batch_lm_dyn_state_bytes(), sba::batch_depth_dyn_state_bytes());
+  const size_t o_active = up(sizeof(sba::BatchDynCtl)), o_done = o_active + up(sizeof(unsigned int) * 2 * B), o_finish = o_done + up(sizeof(int) * B),
+               o_req = o_finish + up(B), o_state = o_req + up(sizeof(sba::BatchDepthPass) * B), o_rows = o_state + up(state_each * B),
+               bytes = o_rows + up(max_rows * sba::kRow * sizeof(double));
+  char* base = nullptr;
+  SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&base), bytes));
+  SBA_TRY_HIP(hipMemsetAsync(base, 0, o_state, b->stream));          // stream-ordered: never a blocking call here
+  b->dyn_ctl = reinterpret_cast<sba::BatchDynCtl*>(base);
+  b->dyn_active = reinterpret_cast<unsigned int*>(base + o_active);
+  b->dyn_done = reinterpret_cast<int*>(base + o_done);
+  b->dyn_finish = reinterpret_cast<unsigned char*>(base + o_finish);
+  b->dyn_depth_req = reinterpret_cast<sba::BatchDepthPass*>(base + o_req);
+  b->dyn_state = base + o_state;
+  b->dyn_partials = reinterpret_cast<double*>(base + o_rows);
+  b->dyn_partial_rows = max_rows;
+  b->dyn_host = reinterpret_cast<unsigned long long*>(b->packs_host + 24 * B) + 2;       // words 2, 3 behind the packs (0: their sequence word)
+  b->dyn_host_dev = reinterpret_cast<unsigned long long*>(b->packs_host_dev + 24 * B) + 2;
+  b->dyn_host[0] = 0; b->dyn_host[1] = 0;
+  b->dyn_seq = 0;
   return SBA_OK;
 }
 
@@ -737,12 +732,8 @@ int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran,
     const bool hybrid = first_passes > 0;
     const int sweep_grid = std::max(1, b->num_cus);
     if (hybrid) {
-      const int rc2 = ensure_dyn(b, sba::batch_depth_dyn_state_bytes(), static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
+      const int rc2 = ensure_dyn(b, static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
       if (rc2) return rc2;
-      if (!b->dyn_depth_req) {
-        SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_depth_req), sizeof(sba::BatchDepthPass) * B));
-        SBA_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&b->dyn_finish), static_cast<size_t>(B)));
-      }
       SBA_TRY_HIP(hipMemsetAsync(b->dyn_finish, 0, static_cast<size_t>(B), b->stream));
     }
     SBA_TRY_HIP(sba::launch_batch_depth_solve(b->store, pl, b->desc_dev, b->depth_const_dev, B, lambda, c, o, b->dplane[0], b->dplane[1],
@@ -1071,7 +1062,7 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
       return SBA_OK;      // pairs that ran out of launches keep SBA_ERR_NUMERIC (cannot happen: the solver's limit ends it first)
     };
     if (dynamic || hybrid) {
-      const int rc2 = ensure_dyn(b, sba::batch_lm_dyn_state_bytes(), static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
+      const int rc2 = ensure_dyn(b, static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
       if (rc2) return rc2;
     }
     if (dynamic) {
