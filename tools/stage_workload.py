@@ -44,8 +44,8 @@ with api.Problem(0) as p:
 out["algorithmic_bytes_per_launch"]["epipolar_moments_kernel<double>"] = n * 48
 out["units_per_launch"]["epipolar_moments_kernel<double>"] = n
 # steady-state pass of the d-only stage: 48 B coordinates + 16 B depths + 16 B scaling + 16 B candidates
-out["algorithmic_bytes_per_launch"]["depth_step_kernel<double>"] = n * 96
-out["units_per_launch"]["depth_step_kernel<double>"] = n
+out["algorithmic_bytes_per_launch"]["depth_step_kernel<double, 1>"] = n * 96   # <ST, AHEAD>
+out["units_per_launch"]["depth_step_kernel<double, 1>"] = n
 del c
 
 B, m = a.pairs, a.pair_matches
