@@ -410,8 +410,11 @@ int sba_batch_sweep_launch_times(sba_batch* b, int mode, int depth_mode, const d
 int sba_batch_step_launch_times(sba_batch* b, int mode, int depth_mode, const double* rot, const double* tran,
                                 const double* d1, const double* d2, double huber_delta, int repeat, float* launch_ms);
 int sba_batch_step_is_fused(const sba_batch* b);
-/* rot / tran are updated in place per pair; summaries (sba_lm_summary[num_pairs]) and status
- * (int[num_pairs], SBA_OK or SBA_ERR_NUMERIC per pair) may be NULL.                                        */
+/* One Levenberg-Marquardt solve per pair (what sba_problem_solve does for one problem).  rot / tran are updated in place per
+ * pair; summaries (sba_lm_summary[num_pairs]) and status (int[num_pairs], SBA_OK or SBA_ERR_NUMERIC per pair) may be NULL.
+ * With one block per pair the solvers run on the device: one launch covers the first sweeps of every pair, pairs that need
+ * more go on in per-iteration launches whose blocks are dealt out to the pairs still iterating (DESIGN.md section 3.5;
+ * SBA_BATCH_DYNAMIC / SBA_BATCH_LM_FIRST_SWEEPS in INTEGRATION.md section 7).                                          */
 int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double* tran, const double* d1,
                     const double* d2, const sba_lm_options* opt, sba_lm_summary* summaries, int* status);
 
@@ -445,8 +448,10 @@ int sba_batch_solve_problem(sba_batch* b, int use_initial_guess, int trials, dou
 
 /* The d-only stage (spherical_bundle_adjuster.cpp:196-197, functor :1004-1063) for EVERY pair of the batch: what
  * sba_problem_solve_depths does for one problem, per pair -- its own trust region, projected line search and convergence;
- * ONE launch: the block that owns a pair runs the pair's whole stage, its solver included (SBA_BATCH_DEVICE_DEPTH=0 in the
- * environment: host solvers in lock-step, one launch per pass -- same results to the bit).  rot, tran: double[num_pairs][3] (frozen);
+ * the solvers run on the device: the block that owns a pair runs the pair's first passes in one launch, pairs that need more go
+ * on in per-pass launches whose blocks are dealt out to the pairs still iterating (SBA_BATCH_DEPTH_FIRST_PASSES=0: the one launch
+ * runs every pair to the end; SBA_BATCH_DEVICE_DEPTH=0: host solvers in lock-step, one launch per pass -- these two agree to the
+ * bit, the default to 1e-9 with equal counts).  rot, tran: double[num_pairs][3] (frozen);
  * needs per-match depths uploaded (the initial values) and refines them on the device, so that a following
  * SBA_DEPTH_PER_MATCH sweep / solve sees them; d12_out (may be NULL): double[offsets[num_pairs]][2], indexed like the uploaded d12
  * (the reference then takes d12_out[offsets[g]][0] and d12_out[offsets[g] + 1][0] as the pair's uniform depths of the rot /
