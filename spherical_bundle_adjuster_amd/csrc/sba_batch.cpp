@@ -732,7 +732,7 @@ int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran,
     const bool hybrid = first_passes > 0;
     const int sweep_grid = std::max(1, b->num_cus);
     if (hybrid) {
-      const int rc2 = ensure_dyn(b, static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
+      const int rc2 = ensure_dyn(b, static_cast<size_t>(sba::kDynOver) * static_cast<size_t>(sweep_grid) + 2 * static_cast<size_t>(B));
       if (rc2) return rc2;
       SBA_TRY_HIP(hipMemsetAsync(b->dyn_finish, 0, static_cast<size_t>(B), b->stream));
     }
@@ -1062,7 +1062,7 @@ int sba_batch_solve(sba_batch* b, int mode, int depth_mode, double* rot, double*
       return SBA_OK;      // pairs that ran out of launches keep SBA_ERR_NUMERIC (cannot happen: the solver's limit ends it first)
     };
     if (dynamic || hybrid) {
-      const int rc2 = ensure_dyn(b, static_cast<size_t>(sweep_grid) + static_cast<size_t>(B));
+      const int rc2 = ensure_dyn(b, static_cast<size_t>(sba::kDynOver) * static_cast<size_t>(sweep_grid) + 2 * static_cast<size_t>(B));
       if (rc2) return rc2;
     }
     if (dynamic) {

@@ -164,7 +164,11 @@ hipError_t batch_blocks_per_cu(int mode, int depth, int store, int kind, bool lo
 // sweep launch whose blocks are dealt out to the pairs that are still iterating, a per-pair step launch and a compaction
 // launch -- all enqueued without waiting; pairs that have converged hand their CUs to the others.
 struct BatchDynCtl { unsigned int nactive[2]; unsigned int pad_[2]; };
-// shares per active pair of a launch of `grid` blocks (1 when there are at least as many pairs as blocks)
+// Shares per active pair of a launch of `grid` blocks: grid / nactive (1 when there are at least as many pairs as blocks).
+// Measured alternative: ceil(4 * grid / nactive) shares, several work items per block -- no block idle at 129 ... 255 active
+// pairs, but every item pays its own fold and row and the per-pair step folds more rows: rot-only stage 2.50 -> 3.28 ms, d-only
+// 7.0 -> 7.5 ms at C5 on the same box (profiles/r03c_dyn_shares_ab.log).  Rows of a launch: nactive * shares <= grid + nactive.
+constexpr unsigned kDynOver = 1;
 SBA_HD inline unsigned dyn_shares(unsigned nactive, unsigned grid) { return nactive == 0u || nactive >= grid ? 1u : grid / nactive; }
 size_t batch_lm_dyn_state_bytes();
 hipError_t launch_batch_dyn_first_list(BatchDynCtl* ctl, unsigned int* active, const int* done, int num_pairs, hipStream_t stream);
