@@ -531,8 +531,8 @@ def c1_leg(device_index: int, n: int = 2048, reps: int = 30):
     """N = 1, after the timed region: BASELINE config C1 -- the reference's real workload, ~2 k matches, main/main.cpp's path
     (reference main/main.cpp:29-32 -> do_bundle_adjustment -> initial_guess -> solve_problem: d-only -> rot-only ->
     tran-only, spherical_bundle_adjuster.cpp:183-217).  End to end on the GPU through the C-ABI (upload, the initial guess
-    from the reference's own subsets, the three stages; problems of this size are served by a resident single-block
-    kernel per stage), wall clock, median of `reps`; beside it the same pipeline with a launch per sweep
+    from the reference's own subsets, the three stages; at this size the d-only stage is ONE launch with its solver on the device and the LM stages command a
+    resident single-block kernel -- `gpu_default`; `gpu_one_launch` / `gpu_resident`: all stages one way or the other), wall clock, median of `reps`; beside it the same pipeline with a launch per sweep
     (SBA_RESIDENT_MAX_N=0), and the oracle's pipeline on the host cores.  Iteration counts of all three must agree."""
     import numpy as np
     try:
@@ -553,25 +553,29 @@ def c1_leg(device_index: int, n: int = 2048, reps: int = 30):
             r2, t2, s2 = p.solve(api.MODE_TRAN, r1, t1, d[0, 0], d[1, 0]); t.append(time.perf_counter())
             return np.diff(t) * 1e6, (sd.num_iterations, sd.num_line_search_steps, s1.num_iterations, s2.num_iterations), (r2, t2)
 
-        def measure(max_n):
-            old = os.environ.get("SBA_RESIDENT_MAX_N")
-            if max_n is None:
-                os.environ.pop("SBA_RESIDENT_MAX_N", None)
-            else:
-                os.environ["SBA_RESIDENT_MAX_N"] = max_n
+        def measure(max_n, one_launch=None):
+            saved = {k: os.environ.get(k) for k in ("SBA_RESIDENT_MAX_N", "SBA_SMALL_ONE_LAUNCH")}
+            for k, v in (("SBA_RESIDENT_MAX_N", max_n), ("SBA_SMALL_ONE_LAUNCH", one_launch)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             try:
                 with api.Problem(device_index) as p:
                     gpu_pipeline(p); gpu_pipeline(p)
                     runs = [gpu_pipeline(p) for _ in range(reps)]
             finally:
-                if old is None:
-                    os.environ.pop("SBA_RESIDENT_MAX_N", None)
-                else:
-                    os.environ["SBA_RESIDENT_MAX_N"] = old
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
             us = np.median(np.array([r[0] for r in runs]), axis=0)
             return {"total_us": float(us.sum()), "upload_us": float(us[0]), "initial_guess_us": float(us[1]), "d_only_us": float(us[2]),
                     "rot_only_us": float(us[3]), "tran_only_us": float(us[4])}, runs[-1][1], runs[-1][2]
-        resident, counts_r, (rot_r, tran_r) = measure(None)
+        default, counts_d, (rot_d, tran_d) = measure(None)                 # default: d-only stage in one launch, LM stages on resident kernels
+        one_launch, counts_o, (rot_o, tran_o) = measure(None, "2")         # every stage one launch, its solver on the device
+        resident, counts_r, (rot_r, tran_r) = measure(None, "0")           # host state machines commanding a resident kernel per stage
         launch, counts_l, (rot_l, tran_l) = measure("0")
         # the oracle's pipeline on the host (numpy 8-point recipe on the same subsets + the C++ restatement of the three stages)
         # ONE OpenMP thread: a 2 048-match sweep is ~0.1 ms of work, and more threads than the cgroup grants cores (the oracle's
@@ -599,14 +603,15 @@ def c1_leg(device_index: int, n: int = 2048, reps: int = 30):
         # the product's T_vec sign may differ from numpy's (the reference never resolves it either): compare the rotation, and
         # the translation only when the 8-point T agreed in sign
         return {"ok": True, "matches": n, "reps": reps,
-                "gpu_resident": resident, "gpu_launch_per_sweep": launch,
+                "gpu_default": default, "gpu_one_launch": one_launch, "gpu_resident": resident, "gpu_launch_per_sweep": launch,
                 "cpu_oracle": {"total_us": float(cus.sum()), "initial_guess_us": float(cus[0]), "d_only_us": float(cus[1]),
                                "rot_only_us": float(cus[2]), "tran_only_us": float(cus[3]), "cores": cores,
                                "what": "numpy restatement of initial_guess on the same subsets + oracle/sba_oracle.cpp stages"},
                 "iterations": {"order": "d-only, d-only line-search contractions, rot-only, tran-only",
-                               "gpu_resident": counts_r, "gpu_launch_per_sweep": counts_l, "cpu_oracle": counts_c,
-                               "equal": bool(counts_r == counts_l == counts_c)},
-                "max_abs_rot_diff_gpu_vs_cpu": float(np.abs(rot_r - rot_c).max()),
+                               "gpu_default": counts_d, "gpu_one_launch": counts_o, "gpu_resident": counts_r, "gpu_launch_per_sweep": counts_l, "cpu_oracle": counts_c,
+                               "equal": bool(counts_d == counts_o == counts_r == counts_l == counts_c)},
+                "max_abs_rot_diff_gpu_vs_cpu": float(np.abs(rot_d - rot_c).max()),
+                "max_abs_rot_diff_one_launch_vs_launch": float(np.abs(rot_o - rot_l).max()),
                 "max_abs_rot_diff_resident_vs_launch": float(np.abs(rot_r - rot_l).max()),
                 "what": "BASELINE config C1 (2 048 synthetic matches): upload -> initial guess (reference's own subsets) -> "
                         "d-only -> rot-only -> tran-only through the C-ABI, wall clock in microseconds (Python call overhead included)"}

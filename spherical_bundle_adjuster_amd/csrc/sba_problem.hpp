@@ -4,6 +4,7 @@
 //   sba_stages.cpp     d-only stage and 8-point initial guess entry points
 // Internal: nothing here is exported from the library.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -76,6 +77,12 @@ struct sba_problem {
   // resident evaluator for small problems (sba_resident.hpp): command record in mapped pinned host memory
   sba::ResidentRecord* res_rec = nullptr;
   sba::ResidentRecord* res_rec_dev = nullptr;
+  // One-launch stages of a small problem (a batch of one pair through batch_depth_solve_kernel / batch_lm_kernel): the pair
+  // descriptor, the d-only stage's R | t, the in / out record and the completion word, in ONE mapped host block the kernel
+  // reads / writes directly (sba_shim.cpp: SmallRecord).
+  void* small_rec = nullptr;
+  void* small_rec_dev = nullptr;
+  unsigned long long small_seq = 0;
   unsigned long long res_cmd_seq = 0;     // sequence number of the last command written
   // Largest problem the LM stages / the d-only stage drive through a resident single-block kernel; above it every sweep /
   // pass is a launch.  Measured cross-over on MI355X (profiles/r03_c1_pipeline.md): one block sweeps 4 096 matches in less
@@ -119,6 +126,25 @@ inline bool is_collective(const sba_problem* p) { return p->comm != nullptr || p
 // call() sends a command and waits for its answer (restarting a kernel that ended itself: idle time-out, trip limit),
 // end() sends QUIT and waits, bounded, for the stream to drain; the destructor ends a session that is still open.
 bool resident_eligible(const sba_problem* p, bool depth_stage);
+// The mapped host block of the one-launch stages (sba_problem::small_rec): what the batch kernels read per pair -- descriptor,
+// frozen R | t of the d-only stage, the in / out record -- and the completion word they publish.
+struct SmallRecord {
+  sba::PairDesc desc;
+  sba::BatchDepthConst cst;
+  sba::BatchLmIo io;
+  volatile unsigned long long seq;
+  unsigned long long pad_[7];
+};
+// Which stages of a small problem run as ONE launch with the solver on the device.  Default: the d-only stage (its step
+// logic is a few microseconds on a GPU lane: 302 us against 376 us through the resident evaluator at 2 048 matches), NOT the LM
+// stages (LmSolver::feed costs 11-16 us on one lane, more than the host's step plus the command round trip: 127 / 89 us against
+// 65 / 47 us for rot-only / tran-only).  SBA_SMALL_ONE_LAUNCH=0: no stage; =2: the LM stages too (A/B, tests).
+inline bool small_one_launch(bool depth_stage) {
+  const char* env = std::getenv("SBA_SMALL_ONE_LAUNCH");
+  if (env && env[0] == '0') return false;
+  if (env && env[0] == '2') return true;
+  return depth_stage;
+}
 class ResidentSession {
  public:
   explicit ResidentSession(sba_problem* p) : p_(p) {}

@@ -527,6 +527,9 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
                             hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(p->res_rec, 0, sizeof(sba::ResidentRecord));
   SBA_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->res_rec_dev), p->res_rec, 0));
+  SBA_HIP_TRY(hipHostMalloc(&p->small_rec, sizeof(sba::shim::SmallRecord), hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(p->small_rec, 0, sizeof(sba::shim::SmallRecord));
+  SBA_HIP_TRY(hipHostGetDevicePointer(&p->small_rec_dev, p->small_rec, 0));
   if (const char* env = std::getenv("SBA_RESIDENT_MAX_N")) {
     const long v = std::atol(env);
     if (v >= 0) p->resident_max_n = p->resident_max_n_depth = static_cast<size_t>(v);
@@ -563,6 +566,7 @@ int sba_problem_destroy(sba_problem* p) {
   if (p->depth_scratch) (void)hipFree(p->depth_scratch);
   if (p->pack_host) (void)hipHostFree(p->pack_host);
   if (p->res_rec) (void)hipHostFree(p->res_rec);
+  if (p->small_rec) (void)hipHostFree(p->small_rec);
   for (void* q : p->upload_pinned) if (q) (void)hipHostFree(q);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -896,6 +900,35 @@ int sba_problem_solve(sba_problem* p, int mode, int depth_mode, double rot[3], d
   // Small, unsharded problems (the reference's real sizes): ONE resident single-block kernel serves every sweep of this
   // stage -- the host LM below is unchanged, only the evaluator talks to a kernel that is already running instead of
   // launching two per iteration (sba_resident.hpp).  SBA_RESIDENT_MAX_N=0 keeps the launch-per-sweep path.
+  // SBA_SMALL_ONE_LAUNCH=2 (not the default: measured slower, sba_problem.hpp) and nobody watching the iterations: the whole
+  // stage as ONE launch -- the problem as a batch of one pair through batch_lm_kernel, the solver on the device.
+  if (sba::shim::resident_eligible(p, false) && !o.verbose && sba::shim::small_one_launch(false)) {
+    SBA_HIP_TRY(hipSetDevice(p->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    sba::shim::SmallRecord* rec = static_cast<sba::shim::SmallRecord*>(p->small_rec);
+    sba::shim::SmallRecord* rec_dev = static_cast<sba::shim::SmallRecord*>(p->small_rec_dev);
+    rec->desc = sba::PairDesc{0ull, p->n, sba::kPairTile, 0ull};
+    for (int a = 0; a < 3; ++a) { rec->io.rot[a] = rot[a]; rec->io.tran[a] = tran[a]; }
+    rec->io.d1 = d1; rec->io.d2 = d2;
+    rec->io.summary = sba_lm_summary{};
+    rec->io.status = SBA_ERR_NUMERIC; rec->io.pad_ = 0;
+    sba::Planes pl;
+    for (int k = 0; k < 3; ++k) { pl.x1[k] = p->coord[k]; pl.x2[k] = p->coord[3 + k]; }
+    pl.d1 = p->dplane[0]; pl.d2 = p->dplane[1];
+    const unsigned long long seq = ++p->small_seq;
+    SBA_HIP_TRY(sba::launch_batch_lm(mode, depth_mode, p->store, p->kind, pl, &rec_dev->desc, &rec_dev->io, o, 1, p->ticket,
+                                     const_cast<unsigned long long*>(&rec_dev->seq), seq, p->stream));
+    rc = sba::wait_for_sequence(&rec->seq, seq, p->stream, "one-launch solve stage", &p->poisoned);
+    if (rc) return rc;
+    for (int a = 0; a < 3; ++a) { rot[a] = rec->io.rot[a]; tran[a] = rec->io.tran[a]; }
+    sba_lm_summary local;
+    sba_lm_summary* s = summary ? summary : &local;
+    *s = rec->io.summary;
+    s->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    s->seconds_eval = s->seconds_total;
+    if (rec->io.status != SBA_OK) return fail(rec->io.status, "LM failed: non-finite or singular normal equations");
+    return SBA_OK;
+  }
   sba::shim::ResidentSession session(p);
   if (sba::shim::resident_eligible(p, false)) {
     SBA_HIP_TRY(hipSetDevice(p->device));

@@ -127,7 +127,37 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
     return SBA_OK;
   };
 
-  // Small, unsharded problem: one resident single-block kernel serves every pass of the stage (sba_resident.hpp); the
+  // Small, unsharded problem: the whole stage in ONE launch -- the problem as a batch of one pair through
+  // batch_depth_solve_kernel: the DepthStageSolver below runs on the device next to its passes (same source), the kernel
+  // copies the result back into the problem's planes itself.  SBA_SMALL_ONE_LAUNCH=0 keeps the resident evaluator.
+  if (sba::shim::resident_eligible(p, true) && sba::shim::small_one_launch(true)) {
+    sba::shim::SmallRecord* rec = static_cast<sba::shim::SmallRecord*>(p->small_rec);
+    sba::shim::SmallRecord* rec_dev = static_cast<sba::shim::SmallRecord*>(p->small_rec_dev);
+    rec->desc = sba::PairDesc{0ull, n, sba::kPairTile, 0ull};
+    for (int i = 0; i < 9; ++i) rec->cst.R[i] = prm.R[i];
+    for (int i = 0; i < 3; ++i) rec->cst.t[i] = tran[i];
+    rec->io = sba::BatchLmIo{};
+    rec->io.status = SBA_ERR_NUMERIC;
+    const unsigned long long seq = ++p->small_seq;
+    SBA_TRY_HIP(sba::launch_batch_depth_solve(p->store, pl, &rec_dev->desc, &rec_dev->cst, 1, lambda, c, o, p->dplane[0], p->dplane[1], c1, c2,
+                                              sc1, sc2, nullptr, nullptr, &rec_dev->io, p->ticket, const_cast<unsigned long long*>(&rec_dev->seq),
+                                              seq, p->stream));
+    const int wrc = sba::wait_for_sequence(&rec->seq, seq, p->stream, "one-launch d-only stage", &p->poisoned);
+    if (wrc) return wrc;
+    *sum = rec->io.summary;
+    sum->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    rc_final = rec->io.status;
+    if (d12_out && n > 0) {
+      sba::DeviceBuffer aos(&p->poisoned);
+      SBA_TRY_HIP(aos.alloc(2 * n * sizeof(double)));
+      SBA_TRY_HIP(sba::launch_planes_to_d12(p->dplane[0], p->dplane[1], n, aos.as<double>(), p->stream));
+      SBA_TRY_HIP(hipMemcpyAsync(d12_out, aos.ptr, 2 * n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      { const int _rc = sba::stream_wait(p->stream, "stream synchronisation", &p->poisoned); if (_rc) return _rc; }
+    }
+    if (rc_final != SBA_OK) return sba::set_error(rc_final, "d-only stage failed: non-finite cost or 5 consecutive invalid steps");
+    return SBA_OK;
+  }
+  // Otherwise (SBA_SMALL_ONE_LAUNCH=0): one resident single-block kernel serves every pass of the stage (sba_resident.hpp); the
   // step logic below is the same, a pass is a command instead of two launches.  The planes alternate as in the launch
   // path: `flip` says that the work planes currently hold the depths and the problem's planes take the candidates.
   sba::shim::ResidentSession session(p);

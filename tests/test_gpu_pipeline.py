@@ -115,7 +115,9 @@ def test_cli_with_eight_point_initial_guess(oracle, tmp_path):
                                      (8192, api.STORE_F64)])
 def test_resident_evaluator_equals_the_launch_path(oracle, n, store, monkeypatch):
     """Small problems (up to 4 096 matches, 2 560 for the d-only stage: BASELINE config C1, the reference's real workload) are solved
-    with ONE resident single-block kernel per stage that the host LM / d-only state machine commands through mapped
+    with ONE launch per stage -- the stage's solver runs on the device, the problem being a batch of one pair for
+    batch_depth_solve_kernel (the default for the d-only stage) / batch_lm_kernel (SBA_SMALL_ONE_LAUNCH=2) -- or with ONE
+    resident single-block kernel per stage (the default for the LM stages; SBA_SMALL_ONE_LAUNCH=0: for all three) that the host LM / d-only state machine commands through mapped
     memory (csrc/sba_resident.hpp) instead of two launches per sweep.  Same state machines, same per-match arithmetic;
     only the fold order of the sums differs (one block instead of a grid + finalize kernel): all three stages must
     agree with the launch-per-sweep path to rounding, with identical iteration / step / contraction counts -- and with
@@ -123,8 +125,10 @@ def test_resident_evaluator_equals_the_launch_path(oracle, n, store, monkeypatch
     c = synthetic.full_rt(n, seed=4200 + n, sigma=5e-4)
     start = np.full((n, 2), 3.0)
     res = {}
-    for name, max_n in (("resident", "100000"), ("launch", "0")):     # force either path at every size (defaults: 4 096 / 2 560)
+    # force each path at every size (defaults: up to 4 096 / 2 560 matches, one launch per stage when nobody watches the iterations)
+    for name, max_n, one_launch in (("one_launch", "100000", "2"), ("resident", "100000", "0"), ("launch", "0", "0")):
         monkeypatch.setenv("SBA_RESIDENT_MAX_N", max_n)
+        monkeypatch.setenv("SBA_SMALL_ONE_LAUNCH", one_launch)
         with api.Problem(0) as p:
             p.upload(c.x1, c.x2, start, store=store)
             d, sd = p.solve_depths(c.rot_init, c.tran_init)
@@ -133,14 +137,18 @@ def test_resident_evaluator_equals_the_launch_path(oracle, n, store, monkeypatch
             r3, t3, s3 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH,
                                  options=api.default_lm_options(tran_param=api.TRAN_SPHERE))
             res[name] = (d, sd, r1, s1, t2, s2, r3, t3, s3)
-    (d, sd, r1, s1, t2, s2, r3, t3, s3), (dL, sdL, r1L, s1L, t2L, s2L, r3L, t3L, s3L) = res["resident"], res["launch"]
-    assert (sd.num_iterations, sd.num_successful_steps, sd.num_line_search_steps, sd.termination) == \
-        (sdL.num_iterations, sdL.num_successful_steps, sdL.num_line_search_steps, sdL.termination)
-    assert np.abs(d - dL).max() <= 1e-10 * max(1.0, np.abs(dL).max())
-    for a, b in ((s1, s1L), (s2, s2L), (s3, s3L)):
-        assert (a.num_iterations, a.num_successful_steps, a.termination) == (b.num_iterations, b.num_successful_steps, b.termination)
-    assert np.abs(r1 - r1L).max() <= 1e-11 and np.abs(t2 - t2L).max() <= 1e-11
-    assert np.abs(r3 - r3L).max() <= 1e-10 and np.abs(t3 - t3L).max() <= 1e-10
+    dL, sdL, r1L, s1L, t2L, s2L, r3L, t3L, s3L = res["launch"]
+    for name in ("one_launch", "resident"):     # one_launch: the stage's solver itself runs on the device (batch kernels on a batch of one)
+        d, sd, r1, s1, t2, s2, r3, t3, s3 = res[name]
+        assert (sd.num_iterations, sd.num_successful_steps, sd.num_line_search_steps, sd.num_evaluations, sd.termination) == \
+            (sdL.num_iterations, sdL.num_successful_steps, sdL.num_line_search_steps, sdL.num_evaluations, sdL.termination), name
+        assert np.abs(d - dL).max() <= 1e-10 * max(1.0, np.abs(dL).max()), name
+        for a, b in ((s1, s1L), (s2, s2L), (s3, s3L)):
+            assert (a.num_iterations, a.num_successful_steps, a.num_evaluations, a.termination, a.final_cost == pytest.approx(b.final_cost, rel=1e-12)) == \
+                (b.num_iterations, b.num_successful_steps, b.num_evaluations, b.termination, True), name
+        assert np.abs(r1 - r1L).max() <= 1e-11 and np.abs(t2 - t2L).max() <= 1e-11, name
+        assert np.abs(r3 - r3L).max() <= 1e-10 and np.abs(t3 - t3L).max() <= 1e-10, name
+    d, sd, r1, s1, t2, s2, r3, t3, s3 = res["one_launch"]
     if store == api.STORE_F64:
         dref, sref, rc = oracle.depth_solve(c.x1, c.x2, c.rot_init, c.tran_init, start)
         assert rc == 0 and sd.num_iterations == sref.num_iterations and np.abs(d - dref).max() <= 1e-9 * max(1.0, np.abs(dref).max())
@@ -156,6 +164,7 @@ def test_resident_kernel_survives_an_idle_host(oracle, monkeypatch):
     with api.Problem(0) as p:
         p.upload(c.x1, c.x2, c.d12)
         r0, t0, s0 = p.solve(api.MODE_RT, c.rot_init, c.tran_init, depth_mode=api.DEPTH_PER_MATCH)
+    monkeypatch.setenv("SBA_SMALL_ONE_LAUNCH", "0")               # the resident evaluator, not the one-launch stages
     monkeypatch.setenv("SBA_RESIDENT_IDLE_S", "0.000001")         # every gap between two commands is "idle"
     with api.Problem(0) as p:
         p.upload(c.x1, c.x2, c.d12)
@@ -200,7 +209,9 @@ def test_bench_default_line_carries_roofline_cpu_baseline_and_c5(tmp_path):
     assert c1["ok"], c1
     assert c1["iterations"]["equal"], c1["iterations"]
     assert c1["max_abs_rot_diff_gpu_vs_cpu"] < 1e-6 and c1["max_abs_rot_diff_resident_vs_launch"] < 1e-10
-    assert 0 < c1["gpu_resident"]["total_us"] and 0 < c1["cpu_oracle"]["total_us"]
+    assert 0 < c1["gpu_default"]["total_us"] and 0 < c1["gpu_one_launch"]["total_us"] and 0 < c1["gpu_resident"]["total_us"]
+    assert 0 < c1["cpu_oracle"]["total_us"]
+    assert c1["max_abs_rot_diff_one_launch_vs_launch"] < 1e-10
     assert b["cold"]["value"] > 0
     c2 = b["c2"]
     assert c2["ok"] and c2["lm"]["termination"].startswith("CONVERGENCE") and 0.1 < c2["roofline"]["frac"] < 1.0
