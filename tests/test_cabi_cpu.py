@@ -107,6 +107,14 @@ def test_null_and_nonsense_arguments_are_errors_not_crashes():
         "batch_eval(null handle)": lambda: lib.sba_batch_eval(None, 0, 0, None, None, None, None, 1.0, None),
         "batch_solve(null handle)": lambda: lib.sba_batch_solve(None, 0, 0, None, None, None, None, None, None, None),
         "batch_step_is_fused(null)": lambda: lib.sba_batch_step_is_fused(None),
+        "batch_set_depths(null handle)": lambda: lib.sba_batch_set_depths(None, None),
+        "batch_solve_depths(null handle)": lambda: lib.sba_batch_solve_depths(None, None, None, 1.0, 1.0, None, None, None, None),
+        "batch_epipolar_moments(null)": lambda: lib.sba_batch_epipolar_moments(None, None),
+        "batch_initial_guess(null handle)": lambda: lib.sba_batch_initial_guess(None, 80, 0.25, 0, None, None, None, None),
+        "batch_solve_problem(null handle)": lambda: lib.sba_batch_solve_problem(None, 1, 80, 0.25, 0, None, None, None, None, None, None, None,
+                                                                              None, None, None),
+        "reference_trial_subsets(bad n)": lambda: lib.sba_reference_trial_subsets(-1, 80, 0.25, None, None),
+        "problem_initial_guess_reference(null)": lambda: lib.sba_problem_initial_guess_reference(None, 80, 0.25, None, None, None),
         "comm_unique_id(null)": lambda: lib.sba_comm_unique_id(None),
         "equi2cube(null image)": lambda: lib.sba_equi2cube(0, None, 64, 128, 16, None),
         "equi2cube_device(null image)": lambda: lib.sba_equi2cube_device(0, null, null, 64, 128, 16, 1, null),
