@@ -727,7 +727,7 @@ int batch_solve_depths_impl(sba_batch* b, const double* rot, const double* tran,
     // Hybrid (default): the one-launch kernel runs the first passes of every pair and hands the pairs that need more over to
     // per-pass launches whose blocks are dealt out to the pairs still iterating -- the CUs of the pairs that are done join in.
     // SBA_BATCH_DEPTH_FIRST_PASSES: the cap of the first launch (default 16; 0: the one-launch kernel runs to the end).
-    int first_passes = 16;
+    int first_passes = 2 * B <= b->num_cus ? 1 : 16;      // few pairs: one block per pair would leave most CUs idle -- hand over at once
     if (const char* env = std::getenv("SBA_BATCH_DEPTH_FIRST_PASSES")) { const int v = std::atoi(env); if (v >= 0 && v <= 100000) first_passes = v; }
     const bool hybrid = first_passes > 0;
     const int sweep_grid = std::max(1, b->num_cus);

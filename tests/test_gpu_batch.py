@@ -184,6 +184,29 @@ def test_batch_depth_stage_hand_over_to_dynamic_shares(store, first, monkeypatch
     assert max(q.num_evaluations for q in s1) > int(first) + 2          # pairs really went on after the hand-over
 
 
+def test_batch_depth_stage_few_long_pairs_spread_over_the_device():
+    """Fewer pairs than CUs: the d-only stage hands every pair over after its first pass, so that each pass of a pair is swept
+    by G / pairs blocks instead of one.  Per pair it must still be the single-problem stage: same counts, depths to 1e-9."""
+    sizes = [120_000, 90_001, 0, 150_000]
+    cs, off, x1, x2, d12 = _make_pairs(sizes, seed0=7300)
+    rot = np.stack([c.rot_init for c in cs]); tran = np.stack([c.tran_init for c in cs])
+    start = np.full_like(d12, 2.0)
+    with api.Batch(0) as b:
+        b.upload(x1, x2, off, start)
+        d, sums, status = b.solve_depths(rot, tran)
+    assert (status == 0).all()
+    for g, c in enumerate(cs):
+        if sizes[g] == 0:
+            continue
+        lo, hi = int(off[g]), int(off[g + 1])
+        with api.Problem(0) as p:
+            p.upload(c.x1, c.x2, start[lo:hi])
+            d1, s1 = p.solve_depths(c.rot_init, c.tran_init)
+        assert (sums[g].num_iterations, sums[g].num_line_search_steps, sums[g].num_evaluations, sums[g].termination) == \
+            (s1.num_iterations, s1.num_line_search_steps, s1.num_evaluations, s1.termination), g
+        assert np.abs(d[lo:hi] - d1).max() <= 1e-9 * max(1.0, np.abs(d1).max()), g
+
+
 @pytest.mark.parametrize("store", [api.STORE_F64, api.STORE_F32], ids=["f64", "f32"])
 @pytest.mark.parametrize("layout", ["0", "1"], ids=["contiguous", "interleaved"])
 def test_batch_initial_guess_matches_single_problem_guesses(store, layout, monkeypatch):
