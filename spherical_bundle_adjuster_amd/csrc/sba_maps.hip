@@ -479,6 +479,7 @@ int build_tiles(Table* t, hipStream_t stream) {
   // At the pole centres every pixel sits in its own 16-byte chunk and its own cache line: staging moves the same number
   // of lines through one more hop (LDS) and quadruples the blocks.  Kept as an option, off by default.
   const bool subtiles = [] { const char* e = std::getenv("SBA_GATHER_SUBTILES"); return e && e[0] == '1'; }();
+  const bool whole_lines = [] { const char* e = std::getenv("SBA_GATHER_LINES"); return e && e[0] == '1'; }();
   std::vector<TileHdr> hdr;
   std::vector<unsigned> chunk_list;
   std::vector<unsigned short> lds_offset;
@@ -501,6 +502,14 @@ int build_tiles(Table* t, hipStream_t stream) {
     }
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    if (whole_lines) {      // SBA_GATHER_LINES=1: every 128-byte line a chunk of the list lies in, whole (8 chunks, clipped to the frame)
+      std::vector<unsigned> lines;
+      for (unsigned c : ids) if (lines.empty() || lines.back() != (c >> 3)) lines.push_back(c >> 3);
+      ids.clear();
+      for (unsigned l : lines)
+        for (unsigned k = 0; k < 8; ++k)
+          if ((static_cast<size_t>(l) * 8 + k + 1) * 16 <= frame_bytes) ids.push_back(l * 8 + k);
+    }
     // stage unless the list is over budget, empty (nothing to read), or its last chunk reaches past the frame (the last
     // frame of a batch must not be read beyond its end)
     const bool stage = !ids.empty() && ids.size() * 16 <= budget && (static_cast<size_t>(ids.back()) + 1) * 16 <= frame_bytes;
