@@ -263,7 +263,10 @@ def run_c5(a):
             passes = max(q.num_evaluations for q in dsums)
             pair_passes = sum(q.num_evaluations for q in dsums)         # a pair leaves the lock-step when it has converged
             one_launch = os.environ.get("SBA_BATCH_DEVICE_DEPTH", "1") != "0"
-            depth = {"seconds": d_s, "driver": "one launch, per-pair solvers on the device" if one_launch else "host lock-step, one launch per pass",
+            cap = os.environ.get("SBA_BATCH_DEPTH_FIRST_PASSES", "16")
+            depth = {"seconds": d_s,
+                     "driver": ((f"per-pair solvers on the device: first {cap} passes in one launch, the rest in launches with dynamic shares" if cap != "0"
+                                 else "per-pair solvers on the device, one launch to the end") if one_launch else "host lock-step, one launch per pass"),
                      "passes_longest_pair": passes, "pair_passes": pair_passes,
                      "iterations_min_max": [min(q.num_iterations for q in dsums), max(q.num_iterations for q in dsums)],
                      "us_per_pass": d_s / max(passes, 1) * 1e6, "all_converged": bool((dstatus == 0).all() and all(q.termination.startswith("CONV") for q in dsums)),
@@ -271,8 +274,9 @@ def run_c5(a):
                      "frac": pair_passes * n * 96 / d_s / 1e9 / HBM_PEAK_GBPS,
                      "ideal_balanced_s": pair_passes * n * 96 / (0.72 * HBM_PEAK_GBPS * 1e9),
                      "what": "sba_batch_solve_depths: every pair's bounded d-only problem (own trust region, line search, convergence), "
-                             "start d = 5; the time is the LONGEST pair's passes on its one CU (pairs need 9-36 iterations), "
-                             "ideal_balanced_s = the same pair-passes spread evenly at the d-only kernel's own 0.72 of peak"}
+                             "start d = 5 (pairs need 9-36 iterations); ideal_balanced_s = the same pair-passes spread evenly over the "
+                             "device at the d-only kernel's own 0.72 of peak (one launch to the end is paced by the longest pair's passes "
+                             "on its one CU; the default hands the late passes to launches whose blocks are dealt to the pairs still iterating)"}
         except Exception as e:      # noqa: BLE001 -- a secondary figure must never take the line down
             depth = {"ok": False, "error": f"{type(e).__name__}: {e}"}
         # the 8-point initial guess of every pair (reference .cpp:47-181): group moments of all pairs in one launch + trials
