@@ -90,6 +90,8 @@ struct sba_problem {
   // behind the 4-16 CUs a launch spreads it over from ~3 000 matches on.  SBA_RESIDENT_MAX_N overrides both (0 = never).
   size_t resident_max_n = 4096;
   size_t resident_max_n_depth = 2560;
+  size_t one_launch_max_n_depth = 4096;     // d-only stage as ONE launch (batch of one pair): 331 us against 362 us with a launch per pass at
+                                            // 4 096 matches, 405 against 344 at 6 144 (tools/small_depth_sizes.py); SBA_RESIDENT_MAX_N sets it too
   double resident_idle_s = 0.25;          // SBA_RESIDENT_IDLE_S: a resident kernel ends itself after this long without a command
 
   sba_allreduce_fn hook = nullptr;

@@ -532,7 +532,7 @@ int sba_problem_create(sba_problem** out, int device, void* stream) {
   SBA_HIP_TRY(hipHostGetDevicePointer(&p->small_rec_dev, p->small_rec, 0));
   if (const char* env = std::getenv("SBA_RESIDENT_MAX_N")) {
     const long v = std::atol(env);
-    if (v >= 0) p->resident_max_n = p->resident_max_n_depth = static_cast<size_t>(v);
+    if (v >= 0) p->resident_max_n = p->resident_max_n_depth = p->one_launch_max_n_depth = static_cast<size_t>(v);
   }
   if (const char* env = std::getenv("SBA_RESIDENT_IDLE_S")) { const double v = std::atof(env); if (v > 0.0 && v <= 10.0) p->resident_idle_s = v; }
   guard.p = nullptr;     // hand over

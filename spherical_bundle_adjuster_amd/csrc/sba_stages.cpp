@@ -130,7 +130,7 @@ int sba_problem_solve_depths(sba_problem* p, const double rot[3], const double t
   // Small, unsharded problem: the whole stage in ONE launch -- the problem as a batch of one pair through
   // batch_depth_solve_kernel: the DepthStageSolver below runs on the device next to its passes (same source), the kernel
   // copies the result back into the problem's planes itself.  SBA_SMALL_ONE_LAUNCH=0 keeps the resident evaluator.
-  if (sba::shim::resident_eligible(p, true) && sba::shim::small_one_launch(true)) {
+  if (p->small_rec != nullptr && p->publish && !collective && n > 0 && n <= p->one_launch_max_n_depth && sba::shim::small_one_launch(true)) {
     sba::shim::SmallRecord* rec = static_cast<sba::shim::SmallRecord*>(p->small_rec);
     sba::shim::SmallRecord* rec_dev = static_cast<sba::shim::SmallRecord*>(p->small_rec_dev);
     rec->desc = sba::PairDesc{0ull, n, sba::kPairTile, 0ull};
